@@ -1,0 +1,165 @@
+/*
+ * rt_mi355x.h -- C ABI of the MI355X (gfx950) replacement for the per-pixel
+ * ray-tracing path of swr06/Ray-Tracer.
+ *
+ * The reference has no plugin or FFI interface; its hot path is entered through
+ *     void TraceThreadFunction(int xstart, int ystart, int xsize, int ysize)
+ * (Source/main.cpp:613), called by TraceScene() (Source/main.cpp:647-659), with
+ * the scene, camera, sizes and framebuffer passed as globals.  This header turns
+ * that seam into explicit arguments.  Every entry point cites what it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types; all structs are PODs with fixed layout;
+ *   - every function returns 0 on success or a negative rt_status; nothing
+ *     throws across the boundary (the reference's path has no error convention:
+ *     its functions are void and PutPixel silently drops out-of-range pixels,
+ *     Source/main.cpp:275);
+ *   - one rt_context drives ONE device; use one context (one process) per GPU;
+ *   - pointers named d_* are device memory of the context's device, all others
+ *     are host memory; `stream` is a hipStream_t passed as void* (NULL = the
+ *     default stream).  Entry points ending in _device enqueue work and return
+ *     without synchronising; the others return when the output is in host memory;
+ *   - images are tightly packed RGB8, index (x + y*width)*3, row 0 = BOTTOM of
+ *     the picture, exactly g_PixelData's layout (Source/main.cpp:76, 273-281);
+ *   - calls on one context must not overlap in time (the reference calls its
+ *     seam from four threads at once, Source/main.cpp:654; a host that wants
+ *     that makes one full-frame call, or serialises tile calls).
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_HIP = -2,          /* a HIP runtime call failed; see rt_last_error() */
+    RT_ERR_NO_DEVICE = -3,    /* no usable gfx950 device / library built without it */
+    RT_ERR_NO_SCENE = -4,     /* rt_set_scene has not been called */
+    RT_ERR_OUT_OF_MEMORY = -5
+} rt_status;
+
+/* enum class Material, Source/main.cpp:354-360 (same values). */
+enum { RT_MAT_GLASS = 0, RT_MAT_DIFFUSE = 1, RT_MAT_METAL = 2, RT_MAT_FUZZYMETAL = 3 };
+
+/* class Sphere, Source/main.cpp:362-391: same field order, 36 bytes.  Diffuse
+ * colours are on a 0..255 scale and metal colours on 0..1, as in the reference's
+ * own scene (Source/main.cpp:520-526). */
+typedef struct rt_sphere {
+    float center[3];
+    float color[3];
+    float radius;
+    int32_t material;
+    float fuzz;
+} rt_sphere;
+
+/* The members Camera::GetRay reads (Source/main.cpp:442, 447-456). */
+typedef struct rt_camera {
+    float origin[3];
+    float bottom_left[3];
+    float horizontal[3];
+    float vertical[3];
+} rt_camera;
+
+/* g_Width, g_Height (Source/main.cpp:74-75), SPP, RAY_DEPTH (:610-611) and the
+ * partition of one frame over several devices. */
+typedef struct rt_params {
+    uint32_t width;        /* frame size in pixels */
+    uint32_t height;
+    uint32_t spp;          /* samples per pixel of the WHOLE frame (the divisor) */
+    int32_t  max_depth;    /* RAY_DEPTH */
+    uint64_t seed;         /* key of the per-(pixel, sample) counter generator */
+    uint32_t sample_begin; /* this call traces samples [sample_begin, */
+    uint32_t sample_count; /*   sample_begin + sample_count); 0 = all spp */
+    uint32_t tile_first;   /* of the 8x8-pixel tiles of the region, numbered row */
+    uint32_t tile_stride;  /*   by row, trace tiles first, first+stride, ...; 0 or 1 = all */
+} rt_params;
+
+typedef struct rt_stats {
+    uint64_t rays;            /* IntersectSceneSpheres calls (Source/main.cpp:562) since the last reset */
+    uint64_t sphere_tests;    /* rays x sphere count */
+    double   last_kernel_ms;  /* device time of the last synchronous call's kernels */
+    double   last_wall_ms;    /* host wall time of the last synchronous call */
+} rt_stats;
+
+typedef struct rt_context rt_context;
+
+/* Library / device ------------------------------------------------------- */
+
+uint32_t rt_abi_version(void);
+const char *rt_status_string(int status);
+/* Message of the last failure on this context ("" if none). */
+const char *rt_last_error(const rt_context *ctx);
+
+/* Creates a context on HIP device `device_id`.  No counterpart in the reference
+ * (it runs on the calling thread). */
+int rt_create(int device_id, rt_context **ctx);
+int rt_destroy(rt_context *ctx);
+
+/* Scene and camera ------------------------------------------------------- */
+
+/* Replaces the global `std::vector<Sphere> Spheres` (Source/main.cpp:520-526):
+ * copies `n` spheres to the device (list order is significant: on equal hit
+ * distance the later sphere wins, Source/main.cpp:492-499, 539-545). */
+int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n);
+
+/* Camera::Camera(lookfrom, lookat, up, fov), Source/main.cpp:420-438 (aspect is
+ * the reference's hard-coded 16:9).  Host-only arithmetic. */
+int rt_camera_init(const float lookfrom[3], const float lookat[3], const float up[3],
+                   float fov_degrees, rt_camera *cam);
+
+/* The path ---------------------------------------------------------------- */
+
+/* TraceThreadFunction(xstart, ystart, xsize, ysize), Source/main.cpp:613-645:
+ * traces the tile and writes its pixels into the caller's full-frame RGB8 host
+ * buffer `rgb` (width*height*3 bytes; pixels outside the tile are untouched). */
+int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
+              int ystart, int xsize, int ysize, uint8_t *rgb);
+
+/* Same, output left in device memory (`d_rgb`: full frame, width*height*3). */
+int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
+                     int ystart, int xsize, int ysize, uint8_t *d_rgb, void *stream);
+
+/* The sample loop of Source/main.cpp:623-636 for samples [sample_begin,
+ * sample_begin+sample_count) and the tiles selected by tile_first/tile_stride:
+ * ADDS each sample's byte colour into `d_sums` (full frame, width*height*3
+ * uint32, index (x + y*width)*3 + channel).  The caller zeroes d_sums. */
+int rt_accumulate_device(rt_context *ctx, const rt_camera *cam, const rt_params *params,
+                         int xstart, int ystart, int xsize, int ysize, uint32_t *d_sums,
+                         void *stream);
+
+/* FinalColor / SPP, ToRGB, PutPixel (Source/main.cpp:638-642) over the tile:
+ * d_rgb = clamp(d_sums / spp_div, 0, 255). */
+int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, uint32_t height,
+                      uint32_t spp_div, int xstart, int ystart, int xsize, int ysize,
+                      uint8_t *d_rgb, void *stream);
+
+/* Deterministic primary-ray map: for every pixel, the index of the sphere that
+ * IntersectSceneSpheres (Source/main.cpp:528-549) selects for the ray through
+ * the pixel centre (jitter 0.5, tmin 0.001f, tmax +inf), or -1.  hits[x + y*width]. */
+int rt_primary_hits(rt_context *ctx, const rt_camera *cam, uint32_t width, uint32_t height,
+                    int32_t *hits);
+int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width, uint32_t height,
+                           int32_t *d_hits, void *stream);
+
+/* IntersectSceneSpheres for caller-supplied rays (Source/main.cpp:528-549):
+ * rays = n x {origin[3], direction[3]} floats; out = n x {int32 index, float T,
+ * float point[3], float normal[3]} (32 bytes, zero where there is no hit). */
+int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out);
+
+/* Counters ---------------------------------------------------------------- */
+
+/* Waits for the context's enqueued work, then reports. */
+int rt_get_stats(rt_context *ctx, rt_stats *stats);
+int rt_reset_stats(rt_context *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

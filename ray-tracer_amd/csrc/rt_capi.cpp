@@ -1,0 +1,561 @@
+// rt_capi.cpp -- the C ABI declared in include/rt_mi355x.h.
+//
+// Host side of the library: owns the device copies of the scene, the work-queue
+// head, the ray counter and the scratch frame buffers, validates arguments and
+// enqueues the kernels of rt_kernels.hip.  There is no CPU implementation of
+// the path behind this boundary: without a HIP device every call fails.
+#include "rt_device.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace rtamd;
+
+struct rt_context {
+    int device = 0;
+    int n_cus = 0;
+    hipStream_t stream = nullptr; // used by the synchronous entry points
+
+    Geom *d_geom = nullptr;
+    rt_sphere *d_spheres = nullptr;
+    uint32_t n_spheres = 0;
+    bool have_scene = false;
+
+    uint32_t *d_chunk_counter = nullptr;
+    unsigned long long *d_rays = nullptr;
+
+    uint32_t *d_sums = nullptr; // scratch for rt_render*/rt_render_device
+    size_t sums_bytes = 0;
+    uint8_t *d_rgb = nullptr;   // scratch for rt_render
+    size_t rgb_bytes = 0;
+
+    uint32_t tile_cap_max = 2048; // spheres per LDS tile (32 KiB)
+    int wg_per_cu_override = 0;
+
+    double last_kernel_ms = 0.0, last_wall_ms = 0.0;
+    std::string error;
+};
+
+namespace {
+
+int fail(rt_context *ctx, int status, const std::string &msg)
+{
+    if (ctx)
+        ctx->error = msg;
+    return status;
+}
+
+int fail_hip(rt_context *ctx, hipError_t e, const char *what)
+{
+    return fail(ctx, RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define RT_HIP(ctx, call)                                  \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess)                              \
+            return fail_hip((ctx), e_, #call);             \
+    } while (0)
+
+struct Region {
+    int x0, y0, w, h;
+};
+
+// Clips TraceThreadFunction's tile to the frame: pixels outside it are dropped
+// by PutPixel in the reference (Source/main.cpp:275) and are not traced here.
+Region clip_region(const rt_params &p, int xs, int ys, int xn, int yn)
+{
+    long x0 = xs, y0 = ys, x1 = (long)xs + xn, y1 = (long)ys + yn;
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 > (long)p.width) x1 = p.width;
+    if (y1 > (long)p.height) y1 = p.height;
+    Region r;
+    r.x0 = (int)x0; r.y0 = (int)y0;
+    r.w = x1 > x0 ? (int)(x1 - x0) : 0;
+    r.h = y1 > y0 ? (int)(y1 - y0) : 0;
+    return r;
+}
+
+int check_params(rt_context *ctx, const rt_camera *cam, const rt_params *p)
+{
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!cam || !p) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null camera or params");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_set_scene has not been called");
+    if (p->width == 0 || p->height == 0 || p->spp == 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "width, height and spp must be positive");
+    if ((uint64_t)p->width * p->height > (1ull << 30))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "frame larger than 2^30 pixels");
+    if (p->max_depth > 4096)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_depth above 4096");
+    if (p->sample_count && (uint64_t)p->sample_begin + p->sample_count > p->spp)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "sample range exceeds spp");
+    if (!p->sample_count && p->sample_begin != 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "sample_begin without sample_count");
+    return RT_OK;
+}
+
+int ensure(rt_context *ctx, void **ptr, size_t *have, size_t want)
+{
+    if (*have >= want)
+        return RT_OK;
+    if (*ptr) {
+        RT_HIP(ctx, hipFree(*ptr));
+        *ptr = nullptr;
+        *have = 0;
+    }
+    hipError_t e = hipMalloc(ptr, want);
+    if (e != hipSuccess)
+        return fail(ctx, RT_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+    *have = want;
+    return RT_OK;
+}
+
+// Enqueues the sample loop for `region` into d_sums.
+int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p, const Region &rg,
+                       uint32_t *d_sums, hipStream_t stream)
+{
+    if (rg.w == 0 || rg.h == 0)
+        return RT_OK;
+
+    TraceArgs a;
+    memset(&a, 0, sizeof a);
+    a.geom = ctx->d_geom;
+    a.spheres = ctx->d_spheres;
+    a.n = ctx->n_spheres;
+    a.cam = *cam;
+    a.width = p->width;
+    a.height = p->height;
+    a.sample_begin = p->sample_begin;
+    a.sample_count = p->sample_count ? p->sample_count : p->spp;
+    a.max_depth = p->max_depth;
+    a.key0 = (uint32_t)p->seed;
+    a.key1 = (uint32_t)(p->seed >> 32);
+    a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
+    a.tiles_x = (uint32_t)(rg.w + kTileW - 1) / kTileW;
+    a.tiles_y = (uint32_t)(rg.h + kTileH - 1) / kTileH;
+    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
+    a.tile_stride = p->tile_stride ? p->tile_stride : 1u;
+    a.tile_first = p->tile_first;
+    if (a.tile_stride == 1u && a.tile_first != 0u)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "tile_first without tile_stride");
+    if (a.tile_first >= a.tile_stride && a.tile_stride > 1u)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "tile_first must be below tile_stride");
+    a.n_chunks = a.tile_first < n_tiles ? (n_tiles - a.tile_first + a.tile_stride - 1u) / a.tile_stride : 0u;
+    if (a.n_chunks == 0u)
+        return RT_OK;
+    a.sums = d_sums;
+    a.rays = ctx->d_rays;
+    a.chunk_counter = ctx->d_chunk_counter;
+
+    // LDS tile: the whole (padded) list when it fits, else tiles of tile_cap_max
+    const uint32_t n_pad = (a.n + (kBlock - 1)) & ~(uint32_t)(kBlock - 1);
+    a.tile_cap = n_pad <= ctx->tile_cap_max ? (n_pad ? n_pad : kBlock) : ctx->tile_cap_max;
+
+    const size_t lds = trace_lds_bytes(a.tile_cap, a.max_depth);
+    if (lds > 160u * 1024u)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_depth too large for the LDS bounce stack");
+    int per_cu = 0;
+    RT_HIP(ctx, trace_occupancy(lds, &per_cu));
+    if (per_cu < 1)
+        return fail(ctx, RT_ERR_HIP, "trace kernel does not fit on a CU");
+    if (ctx->wg_per_cu_override > 0 && ctx->wg_per_cu_override < per_cu)
+        per_cu = ctx->wg_per_cu_override;
+    // every workgroup's 4 waves pull chunks until the queue is empty, so the grid
+    // only needs to fill the chip
+    uint32_t n_wg = (uint32_t)ctx->n_cus * (uint32_t)per_cu;
+    const uint32_t by_chunks = (a.n_chunks + 3u) / 4u;
+    if (n_wg > by_chunks)
+        n_wg = by_chunks;
+
+    RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk_counter, 0, sizeof(uint32_t), stream));
+    RT_HIP(ctx, launch_trace(a, n_wg, stream));
+    return RT_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char *rt_status_string(int status)
+{
+    switch (status) {
+    case RT_OK: return "ok";
+    case RT_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case RT_ERR_HIP: return "HIP runtime error";
+    case RT_ERR_NO_DEVICE: return "no usable HIP device";
+    case RT_ERR_NO_SCENE: return "no scene set";
+    case RT_ERR_OUT_OF_MEMORY: return "out of device memory";
+    default: return "unknown status";
+    }
+}
+
+const char *rt_last_error(const rt_context *ctx) { return ctx ? ctx->error.c_str() : ""; }
+
+int rt_create(int device_id, rt_context **out)
+{
+    if (!out)
+        return RT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return RT_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count)
+        return RT_ERR_INVALID_ARGUMENT;
+    rt_context *ctx = new (std::nothrow) rt_context;
+    if (!ctx)
+        return RT_ERR_OUT_OF_MEMORY;
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
+        delete ctx;
+        return RT_ERR_NO_DEVICE;
+    }
+    ctx->n_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_chunk_counter, 256) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_rays, 256) != hipSuccess ||
+        hipMemset(ctx->d_rays, 0, 256) != hipSuccess) {
+        rt_destroy(ctx);
+        return RT_ERR_HIP;
+    }
+    if (const char *e = getenv("RT_TILE_CAP")) {
+        long v = atol(e);
+        if (v >= kBlock && v <= 8192)
+            ctx->tile_cap_max = (uint32_t)(v / kBlock) * kBlock;
+    }
+    if (const char *e = getenv("RT_WG_PER_CU")) {
+        long v = atol(e);
+        if (v >= 1 && v <= 8)
+            ctx->wg_per_cu_override = (int)v;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+int rt_destroy(rt_context *ctx)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->d_geom) (void)hipFree(ctx->d_geom);
+    if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
+    if (ctx->d_chunk_counter) (void)hipFree(ctx->d_chunk_counter);
+    if (ctx->d_rays) (void)hipFree(ctx->d_rays);
+    if (ctx->d_sums) (void)hipFree(ctx->d_sums);
+    if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    if (n && !spheres)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null sphere list");
+    if (n > (1u << 24))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "more than 2^24 spheres");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipDeviceSynchronize());
+    if (ctx->d_geom) { RT_HIP(ctx, hipFree(ctx->d_geom)); ctx->d_geom = nullptr; }
+    if (ctx->d_spheres) { RT_HIP(ctx, hipFree(ctx->d_spheres)); ctx->d_spheres = nullptr; }
+    ctx->have_scene = false;
+
+    const uint32_t n_pad = (n + (kBlock - 1)) & ~(uint32_t)(kBlock - 1);
+    std::vector<Geom> geom(n_pad ? n_pad : kBlock);
+    memset(geom.data(), 0, geom.size() * sizeof(Geom));
+    for (uint32_t i = 0; i < n; ++i) {
+        geom[i].cx = spheres[i].center[0];
+        geom[i].cy = spheres[i].center[1];
+        geom[i].cz = spheres[i].center[2];
+        // sphere.Radius * sphere.Radius, Source/main.cpp:478: one rounded product
+        volatile float r2 = spheres[i].radius * spheres[i].radius;
+        geom[i].r2 = r2;
+    }
+    if (hipMalloc((void **)&ctx->d_geom, geom.size() * sizeof(Geom)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_spheres, (size_t)(n ? n : 1) * sizeof(rt_sphere)) != hipSuccess)
+        return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for the scene");
+    RT_HIP(ctx, hipMemcpy(ctx->d_geom, geom.data(), geom.size() * sizeof(Geom), hipMemcpyHostToDevice));
+    if (n)
+        RT_HIP(ctx, hipMemcpy(ctx->d_spheres, spheres, (size_t)n * sizeof(rt_sphere), hipMemcpyHostToDevice));
+    ctx->n_spheres = n;
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+// Camera::Camera, Source/main.cpp:420-438, in glm 0.9.8.5's operation order:
+// normalize(v) = v * (1 / sqrt(dot(v, v))), scalar * vector per component.
+int rt_camera_init(const float lookfrom[3], const float lookat[3], const float up[3],
+                   float fov_degrees, rt_camera *cam)
+{
+    if (!lookfrom || !lookat || !up || !cam)
+        return RT_ERR_INVALID_ARGUMENT;
+    auto dot = [](const float *a, const float *b) {
+        const float x = a[0] * b[0], y = a[1] * b[1], z = a[2] * b[2];
+        return (x + y) + z;
+    };
+    auto normalize = [&](const float *v, float *o) {
+        const float inv = 1.0f / std::sqrt(dot(v, v));
+        o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv;
+    };
+    auto cross = [](const float *x, const float *y, float *o) {
+        o[0] = x[1] * y[2] - y[1] * x[2];
+        o[1] = x[2] * y[0] - y[2] * x[0];
+        o[2] = x[0] * y[1] - y[0] * x[1];
+    };
+    const float aspect = 16.0f / 9.0f;
+    const float theta = fov_degrees * 0.01745329251994329576923690768489f;
+    const float half_h = std::tan(theta / 2.0f);
+    const float vh = 2.0f * half_h;
+    const float vw = vh * aspect;
+    const float back[3] = { lookfrom[0] - lookat[0], lookfrom[1] - lookat[1], lookfrom[2] - lookat[2] };
+    float w[3], c[3], u[3], v[3];
+    normalize(back, w);
+    cross(up, w, c);
+    normalize(c, u);
+    cross(w, u, v);
+    for (int i = 0; i < 3; ++i) {
+        cam->origin[i] = lookfrom[i];
+        cam->horizontal[i] = vw * u[i];
+        cam->vertical[i] = vh * v[i];
+        const float a = cam->origin[i] - (cam->horizontal[i] / 2.0f);
+        const float b = a - (cam->vertical[i] / 2.0f);
+        cam->bottom_left[i] = b - w[i];
+    }
+    return RT_OK;
+}
+
+int rt_accumulate_device(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
+                         int ystart, int xsize, int ysize, uint32_t *d_sums, void *stream)
+{
+    int st = check_params(ctx, cam, params);
+    if (st != RT_OK)
+        return st;
+    if (!d_sums)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null d_sums");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const Region rg = clip_region(*params, xstart, ystart, xsize, ysize);
+    return enqueue_accumulate(ctx, cam, params, rg, d_sums, (hipStream_t)stream);
+}
+
+int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, uint32_t height,
+                      uint32_t spp_div, int xstart, int ystart, int xsize, int ysize, uint8_t *d_rgb,
+                      void *stream)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    if (!d_sums || !d_rgb || width == 0 || height == 0 || spp_div == 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad resolve arguments");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    rt_params p;
+    memset(&p, 0, sizeof p);
+    p.width = width; p.height = height;
+    const Region rg = clip_region(p, xstart, ystart, xsize, ysize);
+    ResolveArgs a;
+    a.sums = d_sums; a.rgb = d_rgb;
+    a.width = width; a.height = height; a.spp_div = spp_div;
+    a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
+    RT_HIP(ctx, launch_resolve(a, (hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
+                     int ystart, int xsize, int ysize, uint8_t *d_rgb, void *stream)
+{
+    int st = check_params(ctx, cam, params);
+    if (st != RT_OK)
+        return st;
+    if (!d_rgb)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null d_rgb");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sums_bytes = (size_t)params->width * params->height * 3u * sizeof(uint32_t);
+    st = ensure(ctx, (void **)&ctx->d_sums, &ctx->sums_bytes, sums_bytes);
+    if (st != RT_OK)
+        return st;
+    const Region rg = clip_region(*params, xstart, ystart, xsize, ysize);
+    if (rg.w == 0 || rg.h == 0)
+        return RT_OK;
+    // zero the rows of the region, trace, divide
+    const size_t row_bytes = (size_t)params->width * 3u * sizeof(uint32_t);
+    RT_HIP(ctx, hipMemsetAsync((uint8_t *)ctx->d_sums + (size_t)rg.y0 * row_bytes, 0, (size_t)rg.h * row_bytes, s));
+    st = enqueue_accumulate(ctx, cam, params, rg, ctx->d_sums, s);
+    if (st != RT_OK)
+        return st;
+    ResolveArgs a;
+    a.sums = ctx->d_sums; a.rgb = d_rgb;
+    a.width = params->width; a.height = params->height; a.spp_div = params->spp;
+    a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
+    RT_HIP(ctx, launch_resolve(a, s));
+    return RT_OK;
+}
+
+int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart, int ystart,
+              int xsize, int ysize, uint8_t *rgb)
+{
+    int st = check_params(ctx, cam, params);
+    if (st != RT_OK)
+        return st;
+    if (!rgb)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null rgb");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t frame_bytes = (size_t)params->width * params->height * 3u;
+    st = ensure(ctx, (void **)&ctx->d_rgb, &ctx->rgb_bytes, frame_bytes);
+    if (st != RT_OK)
+        return st;
+    const Region rg = clip_region(*params, xstart, ystart, xsize, ysize);
+    if (rg.w == 0 || rg.h == 0)
+        return RT_OK;
+
+    hipEvent_t e0, e1;
+    RT_HIP(ctx, hipEventCreate(&e0));
+    RT_HIP(ctx, hipEventCreate(&e1));
+    RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    st = rt_render_device(ctx, cam, params, xstart, ystart, xsize, ysize, ctx->d_rgb, ctx->stream);
+    if (st == RT_OK) {
+        hipError_t e = hipEventRecord(e1, ctx->stream);
+        const size_t pitch = (size_t)params->width * 3u;
+        const size_t off = ((size_t)rg.x0 + (size_t)rg.y0 * params->width) * 3u;
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(rgb + off, pitch, ctx->d_rgb + off, pitch, (size_t)rg.w * 3u, (size_t)rg.h,
+                                 hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+                ctx->last_kernel_ms = ms;
+        } else {
+            st = fail_hip(ctx, e, "rt_render copy-back");
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+}
+
+int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width, uint32_t height,
+                           int32_t *d_hits, void *stream)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    if (!cam || !d_hits || width == 0 || height == 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad primary-hit arguments");
+    if (!ctx->have_scene)
+        return fail(ctx, RT_ERR_NO_SCENE, "rt_set_scene has not been called");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    HitsArgs a;
+    a.geom = ctx->d_geom; a.n = ctx->n_spheres; a.cam = *cam;
+    a.width = width; a.height = height; a.hits = d_hits;
+    RT_HIP(ctx, launch_primary_hits(a, (hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_primary_hits(rt_context *ctx, const rt_camera *cam, uint32_t width, uint32_t height, int32_t *hits)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    if (!hits)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null hits");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t bytes = (size_t)width * height * sizeof(int32_t);
+    int32_t *d = nullptr;
+    if (bytes == 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "empty frame");
+    if (hipMalloc((void **)&d, bytes) != hipSuccess)
+        return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for the hit map");
+    int st = rt_primary_hits_device(ctx, cam, width, height, d, ctx->stream);
+    if (st == RT_OK) {
+        hipError_t e = hipMemcpyAsync(hits, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess)
+            st = fail_hip(ctx, e, "rt_primary_hits copy-back");
+    }
+    (void)hipFree(d);
+    ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+}
+
+int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene)
+        return fail(ctx, RT_ERR_NO_SCENE, "rt_set_scene has not been called");
+    if (n == 0)
+        return RT_OK;
+    if (!rays || !out)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null rays or out");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    float *d_rays = nullptr;
+    uint8_t *d_out = nullptr;
+    const size_t in_bytes = (size_t)n * 6u * sizeof(float), out_bytes = (size_t)n * 32u;
+    if (hipMalloc((void **)&d_rays, in_bytes) != hipSuccess || hipMalloc((void **)&d_out, out_bytes) != hipSuccess) {
+        if (d_rays) (void)hipFree(d_rays);
+        return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for rt_intersect");
+    }
+    int st = RT_OK;
+    hipError_t e = hipMemcpyAsync(d_rays, rays, in_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        IntersectArgs a;
+        a.geom = ctx->d_geom; a.spheres = ctx->d_spheres; a.n = ctx->n_spheres;
+        a.rays = d_rays; a.n_rays = n; a.out = d_out;
+        e = launch_intersect(a, ctx->stream);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+        st = fail_hip(ctx, e, "rt_intersect");
+    (void)hipFree(d_rays);
+    (void)hipFree(d_out);
+    return st;
+}
+
+int rt_get_stats(rt_context *ctx, rt_stats *stats)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    if (!stats)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null stats");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipDeviceSynchronize());
+    unsigned long long rays = 0;
+    RT_HIP(ctx, hipMemcpy(&rays, ctx->d_rays, sizeof rays, hipMemcpyDeviceToHost));
+    stats->rays = rays;
+    stats->sphere_tests = rays * (uint64_t)ctx->n_spheres;
+    stats->last_kernel_ms = ctx->last_kernel_ms;
+    stats->last_wall_ms = ctx->last_wall_ms;
+    return RT_OK;
+}
+
+int rt_reset_stats(rt_context *ctx)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipDeviceSynchronize());
+    RT_HIP(ctx, hipMemset(ctx->d_rays, 0, sizeof(unsigned long long)));
+    ctx->last_kernel_ms = ctx->last_wall_ms = 0.0;
+    return RT_OK;
+}
+
+} // extern "C"

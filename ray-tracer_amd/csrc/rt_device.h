@@ -1,0 +1,77 @@
+// rt_device.h -- kernel argument blocks and launch wrappers shared by the HIP
+// kernels (rt_kernels.hip) and the C ABI (rt_capi.cpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_mi355x.h"
+
+namespace rtamd {
+
+// Threads per workgroup of the trace kernel: 4 waves, one per SIMD of a CU.
+constexpr int kTraceThreads = 256;
+// Pixel tile one wave draws its samples from (also rt_params' tile unit).
+constexpr int kTileW = 8;
+constexpr int kTileH = 8;
+// Spheres tested per candidate mask word.
+constexpr int kBlock = 32;
+
+// Geometry record streamed through LDS: centre and radius*radius.
+struct Geom {
+    float cx, cy, cz, r2;
+};
+
+struct TraceArgs {
+    const Geom *geom;          // n records, padded with zeros to a multiple of kBlock
+    const rt_sphere *spheres;  // n records, the caller's list
+    uint32_t n;
+    uint32_t tile_cap;         // spheres per LDS tile, multiple of kBlock
+    rt_camera cam;
+    uint32_t width, height;
+    uint32_t sample_begin, sample_count;
+    int32_t max_depth;
+    uint32_t key0, key1;
+    int32_t x0, y0, w, h;      // traced region
+    uint32_t tiles_x, tiles_y; // 8x8 tiles of the region
+    uint32_t tile_first, tile_stride, n_chunks; // chunk c traces tile tile_first + c*tile_stride
+    uint32_t *sums;            // full frame uint32 x3
+    unsigned long long *rays;  // ray counter
+    uint32_t *chunk_counter;   // work queue head, zeroed before launch
+};
+
+struct ResolveArgs {
+    const uint32_t *sums;
+    uint8_t *rgb;
+    uint32_t width, height, spp_div;
+    int32_t x0, y0, w, h;
+};
+
+struct HitsArgs {
+    const Geom *geom;
+    uint32_t n;
+    rt_camera cam;
+    uint32_t width, height;
+    int32_t *hits;
+};
+
+struct IntersectArgs {
+    const Geom *geom;
+    const rt_sphere *spheres;
+    uint32_t n;
+    const float *rays;
+    uint32_t n_rays;
+    uint8_t *out; // 32 bytes per ray
+};
+
+// Bytes of dynamic LDS the trace kernel needs.
+size_t trace_lds_bytes(uint32_t tile_cap, int32_t max_depth);
+
+hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream);
+hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream);
+hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream);
+hipError_t launch_intersect(const IntersectArgs &a, hipStream_t stream);
+// Resident workgroups per CU of the trace kernel at this LDS size.
+hipError_t trace_occupancy(size_t lds_bytes, int *workgroups_per_cu);
+
+} // namespace rtamd

@@ -1,0 +1,580 @@
+// rt_kernels.hip -- gfx950 kernels for the per-pixel ray-tracing path.
+//
+// What the kernels compute is fixed by the reference, operation by operation
+// (Source/main.cpp, cited per function); how they compute it is CDNA4-specific:
+//
+//   * one lane = one light path.  A wave keeps its 64 lanes busy by refilling
+//     finished lanes from an 8x8-pixel chunk of (pixel, sample) items it pulls
+//     from a global queue (ballot + mbcnt ranks, no per-lane atomics), so waves
+//     never idle on short paths while long ones finish;
+//   * the sphere list is streamed through LDS in tiles of {cx, cy, cz, r*r};
+//     every lane reads the same record (LDS broadcast, conflict free);
+//   * the hot loop only decides `discriminant < 0` per sphere and shifts the
+//     answer into a per-lane 32-bit candidate mask -- no branch, no sqrt, no
+//     divide.  Candidates (a handful per ray) are then resolved in list order
+//     with the reference's exact root selection;
+//   * colour is byte-quantised at every recursion level in the reference, so
+//     the iterative path records the spheres it bounced off in an LDS stack and
+//     replays the per-level byte arithmetic in reverse once it terminates;
+//   * samples are summed as integers with atomics, so any split of samples or
+//     tiles over devices gives bit-identical frames.
+//
+// Build with -ffp-contract=off: every float multiply and add must round on its
+// own, as in the reference's x86-64 build; sqrt and divide are IEEE (hipcc's
+// default -fhip-fp32-correctly-rounded-divide-sqrt).
+#include "rt_device.h"
+
+#include <limits.h>
+#include <math.h>
+
+namespace rtamd {
+namespace {
+
+// ---------------------------------------------------------------------------
+// Counter-based random numbers
+// ---------------------------------------------------------------------------
+
+// Philox4x32-10 block for counter (c0, c1, c2, 0).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4])
+{
+    uint32_t c3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// RandomFloat(), Source/main.cpp:87-92, as libstdc++ maps one 32-bit engine
+// word to [0,1): float(w) / 2^32, and 1.0f replaced by the float below it.
+__device__ __forceinline__ float unit_float(uint32_t w)
+{
+    const float r = (float)w * 0x1p-32f;
+    return r >= 1.0f ? 0.99999994f : r;
+}
+
+// RandomFloat(-1.0f, 1.0f), Source/main.cpp:94-97: evaluated in double, then narrowed.
+__device__ __forceinline__ float range_m1_p1(uint32_t w)
+{
+    const double r = (double)unit_float(w);
+    return (float)(-1.0 + 2.0 * r);
+}
+
+// ---------------------------------------------------------------------------
+// Bytes
+// ---------------------------------------------------------------------------
+
+// static_cast<int>(float) as the reference's x86-64 build executes it: truncate,
+// INT_MIN for NaN and out-of-range; then glm::clamp to 0..255 (Source/main.cpp:117-133).
+__device__ __forceinline__ int to_byte(float v)
+{
+    const int iv = (v < 2147483648.0f && v >= -2147483648.0f) ? (int)v : INT_MIN;
+    return min(max(iv, 0), 255);
+}
+
+// GetGradientColorAtRay + Lerp, Source/main.cpp:461-467, 157-160.
+__device__ __forceinline__ void sky(float dy, int &r, int &g, int &b)
+{
+    const float t = dy * 1.8f;
+    const float omt = 1.0f - t;
+    r = to_byte(omt * 255.0f + t * 128.0f);
+    g = to_byte(omt * 255.0f + t * 178.0f);
+    b = to_byte(omt * 255.0f + t * 255.0f);
+}
+
+// ---------------------------------------------------------------------------
+// Rays
+// ---------------------------------------------------------------------------
+
+struct RayState {
+    float ox, oy, oz, dx, dy, dz;
+    float four_a, two_a; // 4*dot(D,D), 2*dot(D,D)
+};
+
+__device__ __forceinline__ void ray_prepare(RayState &r)
+{
+    const float A = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz; // dot(): products summed left to right
+    r.four_a = 4.0f * A;
+    r.two_a = 2.0f * A;
+}
+
+// Camera::GetRay, Source/main.cpp:440-444, for pixel (i, j) with jitter (ju, jv)
+// in [0,1): u and v are formed in double and narrowed (Source/main.cpp:627-628).
+__device__ __forceinline__ void camera_ray(const rt_camera &cam, uint32_t width, uint32_t height,
+                                           int i, int j, double ju, double jv, RayState &r)
+{
+    const float u = (float)(((double)(float)i + ju) / (double)(float)width);
+    const float v = (float)(((double)(float)j + jv) / (double)(float)height);
+    r.ox = cam.origin[0]; r.oy = cam.origin[1]; r.oz = cam.origin[2];
+    r.dx = ((cam.bottom_left[0] + (cam.horizontal[0] * u)) + (v * cam.vertical[0])) - cam.origin[0];
+    r.dy = ((cam.bottom_left[1] + (cam.horizontal[1] * u)) + (v * cam.vertical[1])) - cam.origin[1];
+    r.dz = ((cam.bottom_left[2] + (cam.horizontal[2] * u)) + (v * cam.vertical[2])) - cam.origin[2];
+    ray_prepare(r);
+}
+
+// Discriminant of RaySphereIntersectionTest, Source/main.cpp:475-479, with the
+// per-ray factors (A) and the per-sphere factor (R*R) computed once: the value
+// is bit-identical because each hoisted factor is a single rounded product.
+__device__ __forceinline__ float discriminant(const RayState &r, const Geom &s, float &B)
+{
+    const float ocx = r.ox - s.cx, ocy = r.oy - s.cy, ocz = r.oz - s.cz;
+    const float d = ocx * r.dx + ocy * r.dy + ocz * r.dz;
+    B = d + d; // float(2.0 * d): doubling is exact
+    const float C = (ocx * ocx + ocy * ocy + ocz * ocz) - s.r2;
+    return B * B - r.four_a * C;
+}
+
+// Root selection of RaySphereIntersectionTest, Source/main.cpp:481-500, against
+// the shrinking ClosestDistance of IntersectSceneSpheres (:539-545).  Returns
+// true when the sphere becomes the closest hit (an equal T is accepted, so the
+// later sphere wins a tie).
+__device__ __forceinline__ bool resolve_candidate(const RayState &r, const Geom &s, float tmin,
+                                                  float &closest)
+{
+    float B;
+    const float disc = discriminant(r, s, B);
+    if (disc < 0.0f)
+        return false;
+    const float sq = sqrtf(disc);
+    float root = (-B - sq) / r.two_a;
+    if (root < tmin || root > closest) {
+        root = (-B + sq) / r.two_a;
+        if (root < tmin || root > closest)
+            return false;
+    }
+    closest = root;
+    return true;
+}
+
+// IntersectSceneSpheres over one LDS tile (Source/main.cpp:534-546).  `tile`
+// holds `count` spheres padded to a multiple of kBlock; `base` is the list
+// index of tile[0].  Phase 1 (uniform, branch free): 32 discriminant signs per
+// mask word.  Phase 2 (divergent, rare): candidates in list order.
+__device__ __forceinline__ void scan_tile(const Geom *__restrict__ tile, uint32_t count,
+                                          uint32_t base, const RayState &r, float tmin,
+                                          float &closest, int &best)
+{
+    for (uint32_t b = 0; b < count; b += kBlock) {
+        uint32_t mask = 0u;
+#pragma unroll
+        for (int j = 0; j < kBlock; ++j) {
+            float B;
+            const float disc = discriminant(r, tile[b + j], B);
+            // the reference takes the hit branch unless disc < 0 (so also for NaN)
+            mask = (mask << 1) | (disc < 0.0f ? 0u : 1u);
+        }
+        if (b + kBlock > count) // padding records of the last block
+            mask &= ~(0xFFFFFFFFu >> (count - b));
+        while (mask) {
+            const int j = __clz((int)mask);
+            mask &= ~(0x80000000u >> j);
+            if (resolve_candidate(r, tile[b + j], tmin, closest))
+                best = (int)(base + b + j);
+        }
+    }
+}
+
+// Hit point and normal, Source/main.cpp:503-514.
+__device__ __forceinline__ void hit_frame(const RayState &r, float t, float cx, float cy, float cz,
+                                          float radius, float &px, float &py, float &pz, float &nx,
+                                          float &ny, float &nz)
+{
+    px = r.ox + (r.dx * t); py = r.oy + (r.dy * t); pz = r.oz + (r.dz * t);
+    nx = (px - cx) / radius; ny = (py - cy) / radius; nz = (pz - cz) / radius;
+    if ((r.dx * nx + r.dy * ny + r.dz * nz) > 0.0f) {
+        nx = -nx; ny = -ny; nz = -nz;
+    }
+}
+
+// GeneratePointInUnitSphere, Source/main.cpp:398-414: one Philox block per attempt.
+__device__ __forceinline__ void point_in_unit_sphere(uint32_t pixel, uint32_t sample,
+                                                     uint32_t &call, uint32_t k0, uint32_t k1,
+                                                     float &x, float &y, float &z)
+{
+    for (;;) {
+        uint32_t w[4];
+        philox4x32_10(pixel, sample, call++, k0, k1, w);
+        x = range_m1_p1(w[0]);
+        y = range_m1_p1(w[1]);
+        z = range_m1_p1(w[2]);
+        if (((x * x) + (y * y) + (z * z)) < 1.0f)
+            return;
+    }
+}
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
+{
+    // number of set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Copies spheres [t0, t0+cnt) of the padded geometry list into the LDS tile.
+__device__ __forceinline__ void load_tile(Geom *tile, const Geom *__restrict__ geom, uint32_t t0,
+                                          uint32_t cnt_padded)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(geom + t0);
+    float4 *dst = reinterpret_cast<float4 *>(tile);
+    for (uint32_t i = threadIdx.x; i < cnt_padded; i += blockDim.x)
+        dst[i] = src[i];
+}
+
+__device__ __forceinline__ uint32_t round_up_block(uint32_t n)
+{
+    return (n + (kBlock - 1)) & ~(uint32_t)(kBlock - 1);
+}
+
+// ---------------------------------------------------------------------------
+// The path kernel: TraceThreadFunction's sample loop + GetRayColor
+// (Source/main.cpp:551-598, 613-645), iterative.
+// ---------------------------------------------------------------------------
+
+template <bool MULTI_TILE>
+__global__ void __launch_bounds__(kTraceThreads) trace_kernel(const TraceArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    Geom *tile = reinterpret_cast<Geom *>(smem);
+    uint32_t *stack = reinterpret_cast<uint32_t *>(smem + (size_t)a.tile_cap * sizeof(Geom));
+    const int stack_levels = a.max_depth > 0 ? a.max_depth : 1;
+    uint32_t *wave_flags = stack + (size_t)stack_levels * kTraceThreads;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t n_pad = round_up_block(a.n);
+
+    if (!MULTI_TILE) {
+        load_tile(tile, a.geom, 0u, n_pad);
+        __syncthreads();
+    }
+
+    // wave-uniform queue state
+    uint32_t w_next = 0u, w_end = 0u;
+    int ch_x0 = 0, ch_y0 = 0, ch_tw = 1, ch_npx = 1;
+    bool queue_empty = (a.sample_count == 0u);
+
+    // per-lane path state
+    bool active = false;
+    RayState ray = {};
+    uint32_t pixel = 0u, sample = 0u, call = 0u;
+    int depth = 0, level = 0;
+    uint32_t n_rays = 0u;
+
+    for (;;) {
+        // ---- refill idle lanes from the wave's chunk, pulling new chunks as needed
+        unsigned long long need = __ballot(!active);
+        while (need != 0ull && !queue_empty) {
+            if (w_next >= w_end) {
+                uint32_t c = 0u;
+                if (lane == 0)
+                    c = atomicAdd(a.chunk_counter, 1u);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c >= a.n_chunks) {
+                    queue_empty = true;
+                    break;
+                }
+                const uint32_t t = a.tile_first + c * a.tile_stride;
+                const uint32_t ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+                ch_x0 = a.x0 + (int)tx * kTileW;
+                ch_y0 = a.y0 + (int)ty * kTileH;
+                ch_tw = min(kTileW, a.x0 + a.w - ch_x0);
+                const int th = min(kTileH, a.y0 + a.h - ch_y0);
+                ch_npx = ch_tw * th;
+                w_next = 0u;
+                w_end = (uint32_t)ch_npx * a.sample_count;
+            }
+            const uint32_t avail = w_end - w_next;
+            const uint32_t rank = lane_rank(need);
+            const bool got = ((need >> lane) & 1ull) && rank < avail;
+            if (got) {
+                const uint32_t item = w_next + rank;
+                const uint32_t s = item / (uint32_t)ch_npx;
+                const uint32_t p = item - s * (uint32_t)ch_npx;
+                const int ly = (int)(p / (uint32_t)ch_tw);
+                const int lx = (int)p - ly * ch_tw;
+                const int px = ch_x0 + lx, py = ch_y0 + ly;
+                pixel = (uint32_t)px + (uint32_t)py * a.width;
+                sample = a.sample_begin + s;
+                call = 0u;
+                if (a.max_depth > 0) { // GetRayColor(ray, 0) is black: nothing to add
+                    uint32_t w[4];
+                    philox4x32_10(pixel, sample, call++, a.key0, a.key1, w);
+                    camera_ray(a.cam, a.width, a.height, px, py, (double)unit_float(w[0]),
+                               (double)unit_float(w[1]), ray);
+                    depth = a.max_depth;
+                    level = 0;
+                    active = true;
+                }
+            }
+            const uint32_t want = (uint32_t)__popcll(need);
+            w_next += want < avail ? want : avail;
+            need &= ~__ballot(got);
+        }
+
+        // ---- termination
+        const bool wave_active = __any(active);
+        if (MULTI_TILE) {
+            if (lane == 0)
+                wave_flags[wave] = wave_active ? 1u : 0u;
+            __syncthreads();
+            const uint32_t any_wave = wave_flags[0] | wave_flags[1] | wave_flags[2] | wave_flags[3];
+            if (any_wave == 0u)
+                break;
+        } else if (!wave_active) {
+            break;
+        }
+
+        // ---- IntersectSceneSpheres(ray, 0.001f, inf), Source/main.cpp:562
+        float closest = INFINITY;
+        int best = -1;
+        if (MULTI_TILE) {
+            for (uint32_t t0 = 0u; t0 < a.n; t0 += a.tile_cap) {
+                const uint32_t cnt = min(a.tile_cap, a.n - t0);
+                __syncthreads(); // everyone is done with the previous tile (and with wave_flags)
+                load_tile(tile, a.geom, t0, round_up_block(cnt));
+                __syncthreads();
+                if (active)
+                    scan_tile(tile, cnt, t0, ray, 0.001f, closest, best);
+            }
+        } else if (active) {
+            scan_tile(tile, a.n, 0u, ray, 0.001f, closest, best);
+        }
+
+        // ---- GetRayColor's branches, Source/main.cpp:562-597
+        if (active) {
+            ++n_rays;
+            bool terminated = false;
+            int cr = 0, cg = 0, cb = 0;
+            if (best < 0) {
+                sky(ray.dy, cr, cg, cb);
+                terminated = true;
+            } else {
+                const rt_sphere *sp = a.spheres + best;
+                const int material = sp->material;
+                if (material == RT_MAT_DIFFUSE || material == RT_MAT_METAL) {
+                    float px, py, pz, nx, ny, nz, rx, ry, rz;
+                    hit_frame(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius,
+                              px, py, pz, nx, ny, nz);
+                    float ndx, ndy, ndz;
+                    if (material == RT_MAT_DIFFUSE) {
+                        // S = Normal + GeneratePointInUnitSphere(), :566
+                        point_in_unit_sphere(pixel, sample, call, a.key0, a.key1, rx, ry, rz);
+                        ndx = nx + rx; ndy = ny + ry; ndz = nz + rz;
+                    } else {
+                        // glm::reflect: I - N * dot(N, I) * 2, then += fuzz * point, :583-584
+                        const float d = nx * ray.dx + ny * ray.dy + nz * ray.dz;
+                        ndx = ray.dx - (nx * d) * 2.0f;
+                        ndy = ray.dy - (ny * d) * 2.0f;
+                        ndz = ray.dz - (nz * d) * 2.0f;
+                        point_in_unit_sphere(pixel, sample, call, a.key0, a.key1, rx, ry, rz);
+                        const float fuzz = sp->fuzz;
+                        ndx = ndx + (fuzz * rx); ndy = ndy + (fuzz * ry); ndz = ndz + (fuzz * rz);
+                    }
+                    stack[level * kTraceThreads + tid] = (uint32_t)best;
+                    ++level;
+                    --depth;
+                    ray.ox = px; ray.oy = py; ray.oz = pz;
+                    ray.dx = ndx; ray.dy = ndy; ray.dz = ndz;
+                    ray_prepare(ray);
+                    if (depth <= 0) { // the child call returns RGB(0,0,0), :555-558
+                        terminated = true;
+                    }
+                } else {
+                    cr = cg = cb = 255; // :594
+                    terminated = true;
+                }
+            }
+            if (terminated) {
+                // unwind the recursion: per level, bytes -> float -> bytes (:569-578, :587-591)
+                for (int l = level - 1; l >= 0; --l) {
+                    const rt_sphere *sp = a.spheres + stack[l * kTraceThreads + tid];
+                    if (sp->material == RT_MAT_DIFFUSE) {
+                        cr >>= 1; cg >>= 1; cb >>= 1;
+                    }
+                    cr = to_byte(sp->color[0] * (float)cr);
+                    cg = to_byte(sp->color[1] * (float)cg);
+                    cb = to_byte(sp->color[2] * (float)cb);
+                }
+                uint32_t *dst = a.sums + (size_t)pixel * 3u;
+                atomicAdd(dst + 0, (uint32_t)cr);
+                atomicAdd(dst + 1, (uint32_t)cg);
+                atomicAdd(dst + 2, (uint32_t)cb);
+                active = false;
+            }
+        }
+    }
+
+    // ---- ray counter: one atomic per wave
+    unsigned long long total = n_rays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        total += __shfl_down(total, off, 64);
+    if (lane == 0 && total != 0ull)
+        atomicAdd(a.rays, total);
+}
+
+// FinalColor / SPP, ToRGB(ivec3), PutPixel -- Source/main.cpp:638-642.
+__global__ void __launch_bounds__(256) resolve_kernel(const ResolveArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = (uint32_t)a.w * (uint32_t)a.h;
+    if (i >= total)
+        return;
+    const uint32_t ly = i / (uint32_t)a.w, lx = i - ly * (uint32_t)a.w;
+    const size_t loc = ((size_t)(a.x0 + (int)lx) + (size_t)(a.y0 + (int)ly) * a.width) * 3u;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t q = a.sums[loc + c] / a.spp_div;
+        a.rgb[loc + c] = (uint8_t)(q > 255u ? 255u : q);
+    }
+}
+
+// Deterministic primary-ray closest-hit map (jitter 0.5): one lane per pixel,
+// the whole workgroup walks the sphere tiles together.
+__global__ void __launch_bounds__(256) primary_hits_kernel(const HitsArgs a, uint32_t tile_cap)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    Geom *tile = reinterpret_cast<Geom *>(smem);
+
+    // 64x4 pixel footprint per workgroup
+    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int py = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const bool inside = px < (int)a.width && py < (int)a.height;
+
+    RayState ray = {};
+    if (inside)
+        camera_ray(a.cam, a.width, a.height, px, py, 0.5, 0.5, ray);
+
+    float closest = INFINITY;
+    int best = -1;
+    for (uint32_t t0 = 0u; t0 < a.n; t0 += tile_cap) {
+        const uint32_t cnt = min(tile_cap, a.n - t0);
+        __syncthreads();
+        load_tile(tile, a.geom, t0, round_up_block(cnt));
+        __syncthreads();
+        if (inside)
+            scan_tile(tile, cnt, t0, ray, 0.001f, closest, best);
+    }
+    if (inside)
+        a.hits[(size_t)px + (size_t)py * a.width] = best;
+}
+
+// IntersectSceneSpheres for caller-supplied rays, with the hit record.
+__global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, uint32_t tile_cap)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    Geom *tile = reinterpret_cast<Geom *>(smem);
+
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inside = i < a.n_rays;
+    RayState ray = {};
+    if (inside) {
+        const float *p = a.rays + (size_t)i * 6u;
+        ray.ox = p[0]; ray.oy = p[1]; ray.oz = p[2];
+        ray.dx = p[3]; ray.dy = p[4]; ray.dz = p[5];
+        ray_prepare(ray);
+    }
+    float closest = INFINITY;
+    int best = -1;
+    for (uint32_t t0 = 0u; t0 < a.n; t0 += tile_cap) {
+        const uint32_t cnt = min(tile_cap, a.n - t0);
+        __syncthreads();
+        load_tile(tile, a.geom, t0, round_up_block(cnt));
+        __syncthreads();
+        if (inside)
+            scan_tile(tile, cnt, t0, ray, 0.001f, closest, best);
+    }
+    if (!inside)
+        return;
+    int32_t *oi = reinterpret_cast<int32_t *>(a.out + (size_t)i * 32u);
+    float *of = reinterpret_cast<float *>(oi);
+    oi[0] = best;
+    if (best >= 0) {
+        const rt_sphere *sp = a.spheres + best;
+        float px, py, pz, nx, ny, nz;
+        hit_frame(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius, px, py, pz,
+                  nx, ny, nz);
+        of[1] = closest;
+        of[2] = px; of[3] = py; of[4] = pz;
+        of[5] = nx; of[6] = ny; of[7] = nz;
+    } else {
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            of[k] = 0.0f;
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// Launch wrappers
+// ---------------------------------------------------------------------------
+
+size_t trace_lds_bytes(uint32_t tile_cap, int32_t max_depth)
+{
+    const size_t levels = max_depth > 0 ? (size_t)max_depth : 1u;
+    return (size_t)tile_cap * sizeof(Geom) + levels * kTraceThreads * sizeof(uint32_t) +
+           4u * sizeof(uint32_t);
+}
+
+hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream)
+{
+    const size_t lds = trace_lds_bytes(a.tile_cap, a.max_depth);
+    const bool multi = a.n > a.tile_cap;
+    if (multi)
+        hipLaunchKernelGGL(trace_kernel<true>, dim3(n_workgroups), dim3(kTraceThreads), lds, stream, a);
+    else
+        hipLaunchKernelGGL(trace_kernel<false>, dim3(n_workgroups), dim3(kTraceThreads), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t trace_occupancy(size_t lds_bytes, int *workgroups_per_cu)
+{
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(workgroups_per_cu, trace_kernel<false>,
+                                                        kTraceThreads, lds_bytes);
+}
+
+hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream)
+{
+    const uint32_t total = (uint32_t)a.w * (uint32_t)a.h;
+    if (total == 0u)
+        return hipSuccess;
+    hipLaunchKernelGGL(resolve_kernel, dim3((total + 255u) / 256u), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+static uint32_t scan_tile_cap(uint32_t n)
+{
+    // spheres per LDS tile for the one-lane-per-ray kernels: up to 32 KiB
+    const uint32_t n_pad = (n + (kBlock - 1)) & ~(uint32_t)(kBlock - 1);
+    return n_pad < 2048u ? (n_pad ? n_pad : kBlock) : 2048u;
+}
+
+hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream)
+{
+    if (a.width == 0u || a.height == 0u)
+        return hipSuccess;
+    const uint32_t cap = scan_tile_cap(a.n);
+    dim3 grid((a.width + 63u) / 64u, (a.height + 3u) / 4u);
+    hipLaunchKernelGGL(primary_hits_kernel, grid, dim3(256), (size_t)cap * sizeof(Geom), stream, a, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_intersect(const IntersectArgs &a, hipStream_t stream)
+{
+    if (a.n_rays == 0u)
+        return hipSuccess;
+    const uint32_t cap = scan_tile_cap(a.n);
+    hipLaunchKernelGGL(intersect_kernel, dim3((a.n_rays + 255u) / 256u), dim3(256),
+                       (size_t)cap * sizeof(Geom), stream, a, cap);
+    return hipGetLastError();
+}
+
+} // namespace rtamd

@@ -1,0 +1,206 @@
+"""ctypes binding of librt_mi355x.so (the C ABI of include/rt_mi355x.h).
+
+Plumbing for the Python tests and bench.py only: it passes plain pointers and
+sizes, never torch types.  Importing it loads the HIP library and fails loudly
+when the library has not been built; there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "librt_mi355x.so")
+
+SPHERE_DTYPE = np.dtype(
+    [("center", "<f4", 3), ("color", "<f4", 3), ("radius", "<f4"), ("material", "<i4"), ("fuzz", "<f4")]
+)
+assert SPHERE_DTYPE.itemsize == 36
+
+MAT_GLASS, MAT_DIFFUSE, MAT_METAL, MAT_FUZZYMETAL = 0, 1, 2, 3
+
+# every symbol include/rt_mi355x.h declares
+EXPORTS = [
+    "rt_abi_version", "rt_status_string", "rt_last_error", "rt_create", "rt_destroy", "rt_set_scene",
+    "rt_camera_init", "rt_render", "rt_render_device", "rt_accumulate_device", "rt_resolve_device",
+    "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_get_stats", "rt_reset_stats",
+]
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("origin", C.c_float * 3),
+        ("bottom_left", C.c_float * 3),
+        ("horizontal", C.c_float * 3),
+        ("vertical", C.c_float * 3),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("spp", C.c_uint32),
+        ("max_depth", C.c_int32),
+        ("seed", C.c_uint64),
+        ("sample_begin", C.c_uint32),
+        ("sample_count", C.c_uint32),
+        ("tile_first", C.c_uint32),
+        ("tile_stride", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("rays", C.c_uint64),
+        ("sphere_tests", C.c_uint64),
+        ("last_kernel_ms", C.c_double),
+        ("last_wall_ms", C.c_double),
+    ]
+
+
+class RtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (raises if it is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(f"{LIB_PATH} not built: run `make -C ray-tracer_amd/csrc` (or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    vp, i, u32 = C.c_void_p, C.c_int, C.c_uint32
+    f3 = C.POINTER(C.c_float)
+    L.rt_abi_version.restype = u32
+    L.rt_status_string.argtypes = [i]
+    L.rt_status_string.restype = C.c_char_p
+    L.rt_last_error.argtypes = [vp]
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_create.argtypes = [i, C.POINTER(vp)]
+    L.rt_destroy.argtypes = [vp]
+    L.rt_set_scene.argtypes = [vp, vp, u32]
+    L.rt_camera_init.argtypes = [f3, f3, f3, C.c_float, C.POINTER(Camera)]
+    L.rt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp]
+    L.rt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, vp]
+    L.rt_accumulate_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, vp]
+    L.rt_resolve_device.argtypes = [vp, vp, u32, u32, u32, i, i, i, i, vp, vp]
+    L.rt_primary_hits.argtypes = [vp, C.POINTER(Camera), u32, u32, vp]
+    L.rt_primary_hits_device.argtypes = [vp, C.POINTER(Camera), u32, u32, vp, vp]
+    L.rt_intersect.argtypes = [vp, vp, u32, vp]
+    L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rt_reset_stats.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def make_camera(lookfrom, lookat, up, fov):
+    cam = Camera()
+    f = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    st = load().rt_camera_init(f(lookfrom), f(lookat), f(up), float(fov), C.byref(cam))
+    if st != 0:
+        raise RtError("rt_camera_init failed")
+    return cam
+
+
+def default_camera():
+    """g_SceneCamera, Source/main.cpp:605-608."""
+    return make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 90.0)
+
+
+def default_scene():
+    """std::vector<Sphere> Spheres, Source/main.cpp:520-526."""
+    s = np.zeros(4, dtype=SPHERE_DTYPE)
+    s[0] = ((-1.0, 0.0, -1.0), (0.8, 0.6, 0.2), 0.5, MAT_METAL, 0.65)
+    s[1] = ((0.0, 0.0, -1.0), (255, 0, 0), 0.5, MAT_DIFFUSE, 0.0)
+    s[2] = ((1.0, 0.0, -1.0), (0.8, 0.8, 0.8), 0.5, MAT_METAL, 0.0)
+    s[3] = ((0.0, -100.5, -1.0), (255, 215, 10), 100.0, MAT_DIFFUSE, 0.0)
+    return s
+
+
+def params(width, height, spp, max_depth, seed=0, sample_begin=0, sample_count=0, tile_first=0, tile_stride=0):
+    return Params(width, height, spp, max_depth, seed, sample_begin, sample_count, tile_first, tile_stride)
+
+
+class Context:
+    """One rt_context on one device."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        self._h = C.c_void_p()
+        st = self._L.rt_create(device, C.byref(self._h))
+        if st != 0:
+            raise RtError(f"rt_create({device}): {self._L.rt_status_string(st).decode()}")
+
+    def close(self):
+        if self._h:
+            self._L.rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            raise RtError(f"{self._L.rt_status_string(st).decode()}: {self._L.rt_last_error(self._h).decode()}")
+
+    def call(self, name, *args):
+        """Raw status of an entry point (for error-path tests)."""
+        return getattr(self._L, name)(self._h, *args)
+
+    def set_scene(self, spheres):
+        spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        self._scene = spheres
+        self._check(self._L.rt_set_scene(self._h, spheres.ctypes.data if len(spheres) else None, len(spheres)))
+
+    def render(self, cam, p, tile=None, rgb=None, fill=255):
+        if tile is None:
+            tile = (0, 0, p.width, p.height)
+        if rgb is None:
+            rgb = np.full((p.height, p.width, 3), fill, dtype=np.uint8)
+        self._check(self._L.rt_render(self._h, C.byref(cam), C.byref(p), *tile, rgb.ctypes.data))
+        return rgb
+
+    def render_device(self, cam, p, d_rgb, tile=None, stream=None):
+        if tile is None:
+            tile = (0, 0, p.width, p.height)
+        self._check(self._L.rt_render_device(self._h, C.byref(cam), C.byref(p), *tile, d_rgb, stream))
+
+    def accumulate_device(self, cam, p, d_sums, tile=None, stream=None):
+        if tile is None:
+            tile = (0, 0, p.width, p.height)
+        self._check(self._L.rt_accumulate_device(self._h, C.byref(cam), C.byref(p), *tile, d_sums, stream))
+
+    def resolve_device(self, d_sums, width, height, spp_div, d_rgb, tile=None, stream=None):
+        if tile is None:
+            tile = (0, 0, width, height)
+        self._check(self._L.rt_resolve_device(self._h, d_sums, width, height, spp_div, *tile, d_rgb, stream))
+
+    def primary_hits(self, cam, width, height):
+        out = np.empty((height, width), dtype=np.int32)
+        self._check(self._L.rt_primary_hits(self._h, C.byref(cam), width, height, out.ctypes.data))
+        return out
+
+    def primary_hits_device(self, cam, width, height, d_hits, stream=None):
+        self._check(self._L.rt_primary_hits_device(self._h, C.byref(cam), width, height, d_hits, stream))
+
+    def intersect(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        out = np.zeros(len(rays), dtype=np.dtype([("index", "<i4"), ("t", "<f4"), ("point", "<f4", 3), ("normal", "<f4", 3)]))
+        self._check(self._L.rt_intersect(self._h, rays.ctypes.data, len(rays), out.ctypes.data))
+        return out
+
+    def stats(self):
+        s = Stats()
+        self._check(self._L.rt_get_stats(self._h, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._check(self._L.rt_reset_stats(self._h))
