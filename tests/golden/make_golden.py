@@ -1,0 +1,138 @@
+"""Regenerates tests/golden/ by running the REAL reference (oracle/_ref/ref_harness).
+
+Run in the build container only (it needs /root/reference to build the harness):
+    make -C oracle && python tests/golden/make_golden.py
+Every fixture is data: inputs and the outputs the reference's own code produced.
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "ray-tracer_amd", "python"))
+import scenes  # noqa: E402
+
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+
+
+def run(*args):
+    return subprocess.check_output([HARNESS] + [str(a) for a in args], text=True)
+
+
+def fnv1a64(b):
+    h = 0xCBF29CE484222325
+    for x in bytes(b):
+        h = ((h ^ x) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def cam_args(cam):
+    lookfrom, lookat, up, fov = cam
+    return [*lookfrom, *lookat, *up, fov]
+
+
+def main():
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    kat = {}
+
+    # ---- known answers of the reference's helpers
+    out = run("kat")
+    m = re.search(r"sizeof Sphere (\d+) Ray (\d+) RayHitRecord (\d+) RGB (\d+)", out)
+    kat["sizeof"] = dict(zip(["Sphere", "Ray", "RayHitRecord", "RGB"], map(int, m.groups())))
+    m = re.search(r"centre dir (\S+) (\S+) (\S+) hit (\d) index (-?\d+) T (\S+) N (\S+) (\S+) (\S+)", out)
+    g = m.groups()
+    kat["centre_ray"] = {"dir": list(map(float, g[0:3])), "hit": int(g[3]), "index": int(g[4]), "T": float(g[5]),
+                         "N": list(map(float, g[6:9]))}
+    kat["random_float_bits"] = [int(x, 16) for x in re.findall(r"draw \d+ \S+ (0x[0-9a-f]+)", out)]
+
+    # ---- default scene, shipped configuration (1024x576, 100 spp, depth 10)
+    strip = os.path.join(tmp, "c1_32.rgb")
+    out = run("c1", 32, strip)
+    img = np.fromfile(strip, dtype=np.uint8).reshape(576, 1024, 3)
+    assert (img[:, 32:] == 255).all()
+    np.save(os.path.join(HERE, "c1_strip32.npy"), np.ascontiguousarray(img[:, :32]))
+    kat["c1_strip32_fnv"] = "%016x" % fnv1a64(img.tobytes())
+    kat["c1_strip32_pixels"] = {f"{x},{y}": img[y, x].tolist() for (x, y) in
+                                [(16, 0), (16, 100), (16, 287), (16, 288), (16, 400), (16, 575)]}
+    full = os.path.join(tmp, "c1_full.rgb")
+    out = run("c1", 1024, full)
+    img = np.fromfile(full, dtype=np.uint8).reshape(576, 1024, 3)
+    kat["c1_full_fnv"] = re.search(r"fnv ([0-9a-f]+)", out).group(1)
+    assert kat["c1_full_fnv"] == "%016x" % fnv1a64(img.tobytes())
+    # rows 280..295 of the full frame (sphere silhouettes + horizon), all columns
+    np.save(os.path.join(HERE, "c1_full_rows280_296.npy"), np.ascontiguousarray(img[280:296]))
+
+    # ---- deterministic primary hit maps, 1920x1080
+    f = os.path.join(tmp, "c2.i32")
+    out = run("hits", 1920, 1080, f)
+    h = np.fromfile(f, dtype=np.int32).reshape(1080, 1920)
+    np.savez_compressed(os.path.join(HERE, "c2_default_hits.npz"), hits=h)
+    kat["c2_default_fnv"] = re.search(r"fnv ([0-9a-f]+)", out).group(1)
+    kat["c2_default_hist"] = {str(k): int(v) for k, v in zip(*np.unique(h, return_counts=True))}
+
+    c3 = scenes.random_spheres(500)
+    scene_path = os.path.join(HERE, "scene_c3_500.bin")
+    c3.tofile(scene_path)
+    cam = cam_args(scenes.RANDOM_SPHERES_CAMERA)
+    out = run("hits", 1920, 1080, f, scene_path, *cam)
+    h = np.fromfile(f, dtype=np.int32).reshape(1080, 1920)
+    np.savez_compressed(os.path.join(HERE, "c2_c3scene_hits.npz"), hits=h)
+    kat["c2_c3scene_fnv"] = re.search(r"fnv ([0-9a-f]+)", out).group(1)
+
+    # ---- 500-sphere scene through the reference's sample loop (one mt19937 stream)
+    f = os.path.join(tmp, "c3.rgb")
+    out = run("render", scene_path, *cam, 64, 36, 16, 8, 0, 64, f)
+    np.save(os.path.join(HERE, "c3_mt_64x36_spp16_d8.npy"), np.fromfile(f, dtype=np.uint8).reshape(36, 64, 3))
+
+    # ---- converged images for the statistical comparison
+    out = run("render", "-", "-", 256, 144, 4096, 10, 0, 256, f)
+    np.save(os.path.join(HERE, "c1_converged_256x144_spp4096_d10.npy"),
+            np.fromfile(f, dtype=np.uint8).reshape(144, 256, 3))
+    out = run("render", scene_path, *cam, 128, 72, 1024, 8, 0, 128, f)
+    np.save(os.path.join(HERE, "c3_converged_128x72_spp1024_d8.npy"),
+            np.fromfile(f, dtype=np.uint8).reshape(72, 128, 3))
+
+    # ---- per-function vectors
+    rs = np.random.RandomState(2024)
+    dirs = rs.uniform(-2.0, 2.0, size=(512, 3)).astype(np.float32)
+    dirs[:8, 1] = [0.0, 1.0, -1.0, 1.0 / 1.8, 0.5555556, 1e-8, 3.0e9, -3.0e9]
+    fin, fout = os.path.join(tmp, "sky.in"), os.path.join(tmp, "sky.out")
+    dirs.tofile(fin)
+    run("sky", len(dirs), fin, fout)
+    np.savez_compressed(os.path.join(HERE, "sky_vectors.npz"), dirs=dirs,
+                        rgb=np.fromfile(fout, dtype=np.uint8).reshape(-1, 3))
+
+    rec = np.dtype([("index", "<i4"), ("t", "<f4"), ("point", "<f4", 3), ("normal", "<f4", 3)])
+    for name, scene_file, scene in (("default", "-", scenes.default_scene()), ("c3scene", scene_path, c3)):
+        n = 4096
+        rays = np.empty((n, 6), dtype=np.float32)
+        rays[:, :3] = rs.uniform(-6.0, 6.0, size=(n, 3))
+        rays[:, 1] = np.abs(rays[:, 1]) * 0.5
+        rays[:, 3:] = rs.uniform(-1.5, 1.5, size=(n, 3))
+        # a quarter of the rays start ON a sphere surface (the tmin = 0.001 case of bounce rays)
+        k = n // 4
+        idx = rs.randint(0, len(scene), size=k)
+        nrm = rs.normal(size=(k, 3)).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        rays[:k, :3] = scene["center"][idx] + scene["radius"][idx, None] * nrm
+        # and some start inside a sphere
+        rays[k:k + 64, :3] = scene["center"][idx[:64]] + 0.3 * scene["radius"][idx[:64], None] * nrm[:64]
+        fin, fout = os.path.join(tmp, "rays.in"), os.path.join(tmp, "rays.out")
+        rays.tofile(fin)
+        run("isect", scene_file, n, fin, fout)
+        np.savez_compressed(os.path.join(HERE, f"isect_{name}.npz"), rays=rays,
+                            out=np.fromfile(fout, dtype=rec))
+
+    with open(os.path.join(HERE, "kat.json"), "w") as fp:
+        json.dump(kat, fp, indent=1, sort_keys=True)
+    print(json.dumps(kat, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
