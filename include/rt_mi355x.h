@@ -84,6 +84,8 @@ typedef struct rt_params {
 typedef struct rt_stats {
     uint64_t rays;            /* IntersectSceneSpheres calls (Source/main.cpp:562) since the last reset */
     uint64_t sphere_tests;    /* rays x sphere count */
+    uint64_t wave_passes;     /* passes of a 64-lane wave over the sphere list; rays / (64 * wave_passes)
+                                 is the fraction of lanes that carried a ray */
     double   last_kernel_ms;  /* device time of the last synchronous call's kernels */
     double   last_wall_ms;    /* host wall time of the last synchronous call */
 } rt_stats;
@@ -152,6 +154,20 @@ int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width
  * rays = n x {origin[3], direction[3]} floats; out = n x {int32 index, float T,
  * float point[3], float normal[3]} (32 bytes, zero where there is no hit). */
 int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out);
+
+/* Tuning (no counterpart in the reference) ---------------------------------- */
+
+typedef enum rt_option {
+    /* 1 (default): the sphere scan flags candidates with a fused, conservatively
+     * widened discriminant test and resolves them with the reference's exact
+     * arithmetic; 0: the scan evaluates the reference's unfused discriminant for
+     * every sphere.  Both give bit-identical results; 0 exists to prove it. */
+    RT_OPT_FILTER = 0,
+    RT_OPT_TILE_SPHERES = 1,      /* spheres per LDS tile, 32..8192 (default 2048) */
+    RT_OPT_WORKGROUPS_PER_CU = 2  /* cap on resident workgroups per CU, 0 = occupancy limit */
+} rt_option;
+
+int rt_set_option(rt_context *ctx, int option, int64_t value);
 
 /* Counters ---------------------------------------------------------------- */
 

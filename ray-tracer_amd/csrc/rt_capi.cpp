@@ -22,10 +22,14 @@ struct rt_context {
     int n_cus = 0;
     hipStream_t stream = nullptr; // used by the synchronous entry points
 
-    Geom *d_geom = nullptr;
+    Geom *d_geom_exact = nullptr;  // {centre, fl(r*r)}
+    Geom *d_geom_filter = nullptr; // {centre, r*r*(1 + 2^-16)}
+    float *d_r2 = nullptr;         // fl(r*r)
     rt_sphere *d_spheres = nullptr;
     uint32_t n_spheres = 0;
     bool have_scene = false;
+    bool scene_tame = false;       // every sphere within the conservative filter's preconditions
+    int filter = kFilterConservative;
 
     uint32_t *d_chunk_counter = nullptr;
     unsigned long long *d_rays = nullptr;
@@ -126,7 +130,9 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
 
     TraceArgs a;
     memset(&a, 0, sizeof a);
-    a.geom = ctx->d_geom;
+    a.filter = ctx->scene_tame ? ctx->filter : (int)kFilterExact;
+    a.geom = a.filter == kFilterExact ? ctx->d_geom_exact : ctx->d_geom_filter;
+    a.r2 = ctx->d_r2;
     a.spheres = ctx->d_spheres;
     a.n = ctx->n_spheres;
     a.cam = *cam;
@@ -229,16 +235,6 @@ int rt_create(int device_id, rt_context **out)
         rt_destroy(ctx);
         return RT_ERR_HIP;
     }
-    if (const char *e = getenv("RT_TILE_CAP")) {
-        long v = atol(e);
-        if (v >= kBlock && v <= 8192)
-            ctx->tile_cap_max = (uint32_t)(v / kBlock) * kBlock;
-    }
-    if (const char *e = getenv("RT_WG_PER_CU")) {
-        long v = atol(e);
-        if (v >= 1 && v <= 8)
-            ctx->wg_per_cu_override = (int)v;
-    }
     *out = ctx;
     return RT_OK;
 }
@@ -249,7 +245,9 @@ int rt_destroy(rt_context *ctx)
         return RT_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    if (ctx->d_geom) (void)hipFree(ctx->d_geom);
+    if (ctx->d_geom_exact) (void)hipFree(ctx->d_geom_exact);
+    if (ctx->d_geom_filter) (void)hipFree(ctx->d_geom_filter);
+    if (ctx->d_r2) (void)hipFree(ctx->d_r2);
     if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
     if (ctx->d_chunk_counter) (void)hipFree(ctx->d_chunk_counter);
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
@@ -270,27 +268,48 @@ int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "more than 2^24 spheres");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipDeviceSynchronize());
-    if (ctx->d_geom) { RT_HIP(ctx, hipFree(ctx->d_geom)); ctx->d_geom = nullptr; }
+    if (ctx->d_geom_exact) { RT_HIP(ctx, hipFree(ctx->d_geom_exact)); ctx->d_geom_exact = nullptr; }
+    if (ctx->d_geom_filter) { RT_HIP(ctx, hipFree(ctx->d_geom_filter)); ctx->d_geom_filter = nullptr; }
+    if (ctx->d_r2) { RT_HIP(ctx, hipFree(ctx->d_r2)); ctx->d_r2 = nullptr; }
     if (ctx->d_spheres) { RT_HIP(ctx, hipFree(ctx->d_spheres)); ctx->d_spheres = nullptr; }
     ctx->have_scene = false;
 
     const uint32_t n_pad = (n + (kBlock - 1)) & ~(uint32_t)(kBlock - 1);
-    std::vector<Geom> geom(n_pad ? n_pad : kBlock);
-    memset(geom.data(), 0, geom.size() * sizeof(Geom));
+    const size_t cnt = n_pad ? n_pad : kBlock;
+    std::vector<Geom> exact(cnt), filt(cnt);
+    std::vector<float> r2(cnt, 0.0f);
+    memset(exact.data(), 0, cnt * sizeof(Geom));
+    memset(filt.data(), 0, cnt * sizeof(Geom));
+    bool tame = true;
     for (uint32_t i = 0; i < n; ++i) {
-        geom[i].cx = spheres[i].center[0];
-        geom[i].cy = spheres[i].center[1];
-        geom[i].cz = spheres[i].center[2];
+        const rt_sphere &sp = spheres[i];
         // sphere.Radius * sphere.Radius, Source/main.cpp:478: one rounded product
-        volatile float r2 = spheres[i].radius * spheres[i].radius;
-        geom[i].r2 = r2;
+        volatile float rr = sp.radius * sp.radius;
+        r2[i] = rr;
+        exact[i].cx = filt[i].cx = sp.center[0];
+        exact[i].cy = filt[i].cy = sp.center[1];
+        exact[i].cz = filt[i].cz = sp.center[2];
+        exact[i].r2 = rr;
+        // widened radius of the conservative filter, rounded up
+        volatile float wide = rr + rr * 0x1p-16f;
+        filt[i].r2 = std::nextafter((float)wide, INFINITY);
+        // preconditions of the filter's error bound: magnitudes below 2^29, r*r at least 2^-60
+        const float m = std::fmax(std::fmax(std::fabs(sp.center[0]), std::fabs(sp.center[1])),
+                                  std::fmax(std::fabs(sp.center[2]), std::fabs(sp.radius)));
+        if (!(m < 0x1p29f) || !(rr >= 0x1p-60f))
+            tame = false;
     }
-    if (hipMalloc((void **)&ctx->d_geom, geom.size() * sizeof(Geom)) != hipSuccess ||
+    if (hipMalloc((void **)&ctx->d_geom_exact, cnt * sizeof(Geom)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_geom_filter, cnt * sizeof(Geom)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_r2, cnt * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_spheres, (size_t)(n ? n : 1) * sizeof(rt_sphere)) != hipSuccess)
         return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for the scene");
-    RT_HIP(ctx, hipMemcpy(ctx->d_geom, geom.data(), geom.size() * sizeof(Geom), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_geom_exact, exact.data(), cnt * sizeof(Geom), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_geom_filter, filt.data(), cnt * sizeof(Geom), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_r2, r2.data(), cnt * sizeof(float), hipMemcpyHostToDevice));
     if (n)
         RT_HIP(ctx, hipMemcpy(ctx->d_spheres, spheres, (size_t)n * sizeof(rt_sphere), hipMemcpyHostToDevice));
+    ctx->scene_tame = tame;
     ctx->n_spheres = n;
     ctx->have_scene = true;
     return RT_OK;
@@ -460,7 +479,10 @@ int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width
         return fail(ctx, RT_ERR_NO_SCENE, "rt_set_scene has not been called");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     HitsArgs a;
-    a.geom = ctx->d_geom; a.n = ctx->n_spheres; a.cam = *cam;
+    a.conservative = (ctx->scene_tame && ctx->filter != kFilterExact) ? 1 : 0;
+    a.geom = a.conservative ? ctx->d_geom_filter : ctx->d_geom_exact;
+    a.r2 = ctx->d_r2;
+    a.n = ctx->n_spheres; a.cam = *cam;
     a.width = width; a.height = height; a.hits = d_hits;
     RT_HIP(ctx, launch_primary_hits(a, (hipStream_t)stream));
     return RT_OK;
@@ -515,7 +537,10 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out)
     hipError_t e = hipMemcpyAsync(d_rays, rays, in_bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         IntersectArgs a;
-        a.geom = ctx->d_geom; a.spheres = ctx->d_spheres; a.n = ctx->n_spheres;
+        a.conservative = (ctx->scene_tame && ctx->filter != kFilterExact) ? 1 : 0;
+        a.geom = a.conservative ? ctx->d_geom_filter : ctx->d_geom_exact;
+        a.r2 = ctx->d_r2;
+        a.spheres = ctx->d_spheres; a.n = ctx->n_spheres;
         a.rays = d_rays; a.n_rays = n; a.out = d_out;
         e = launch_intersect(a, ctx->stream);
     }
@@ -530,6 +555,34 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out)
     return st;
 }
 
+int rt_set_option(rt_context *ctx, int option, int64_t value)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    switch (option) {
+    case RT_OPT_FILTER:
+        if (value == 0) ctx->filter = kFilterExact;
+        else if (value == 1) ctx->filter = kFilterConservative;
+#ifdef RT_DIAGNOSTIC_KERNELS
+        else if (value == 2) ctx->filter = kFilterNoResolve;
+#endif
+        else return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_FILTER takes 0 or 1");
+        return RT_OK;
+    case RT_OPT_TILE_SPHERES:
+        if (value < kBlock || value > 8192)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_TILE_SPHERES takes 32..8192");
+        ctx->tile_cap_max = (uint32_t)(value / kBlock) * kBlock;
+        return RT_OK;
+    case RT_OPT_WORKGROUPS_PER_CU:
+        if (value < 0 || value > 8)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_WORKGROUPS_PER_CU takes 0..8");
+        ctx->wg_per_cu_override = (int)value;
+        return RT_OK;
+    default:
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option");
+    }
+}
+
 int rt_get_stats(rt_context *ctx, rt_stats *stats)
 {
     if (!ctx)
@@ -538,10 +591,11 @@ int rt_get_stats(rt_context *ctx, rt_stats *stats)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null stats");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipDeviceSynchronize());
-    unsigned long long rays = 0;
-    RT_HIP(ctx, hipMemcpy(&rays, ctx->d_rays, sizeof rays, hipMemcpyDeviceToHost));
-    stats->rays = rays;
-    stats->sphere_tests = rays * (uint64_t)ctx->n_spheres;
+    unsigned long long counters[2] = { 0, 0 };
+    RT_HIP(ctx, hipMemcpy(counters, ctx->d_rays, sizeof counters, hipMemcpyDeviceToHost));
+    stats->rays = counters[0];
+    stats->sphere_tests = counters[0] * (uint64_t)ctx->n_spheres;
+    stats->wave_passes = counters[1];
     stats->last_kernel_ms = ctx->last_kernel_ms;
     stats->last_wall_ms = ctx->last_wall_ms;
     return RT_OK;
@@ -553,7 +607,7 @@ int rt_reset_stats(rt_context *ctx)
         return RT_ERR_INVALID_ARGUMENT;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipDeviceSynchronize());
-    RT_HIP(ctx, hipMemset(ctx->d_rays, 0, sizeof(unsigned long long)));
+    RT_HIP(ctx, hipMemset(ctx->d_rays, 0, 2 * sizeof(unsigned long long)));
     ctx->last_kernel_ms = ctx->last_wall_ms = 0.0;
     return RT_OK;
 }

@@ -17,15 +17,25 @@ constexpr int kTileH = 8;
 // Spheres tested per candidate mask word.
 constexpr int kBlock = 32;
 
-// Geometry record streamed through LDS: centre and radius*radius.
+// Geometry record streamed through LDS: centre and a squared radius (the exact
+// fl(r*r) for the exact filter, r*r*(1 + 2^-16) for the conservative one).
 struct Geom {
     float cx, cy, cz, r2;
 };
 
+// How the scan decides which spheres need the exact root evaluation.
+enum {
+    kFilterExact = 0,        // the reference's own discriminant, unfused
+    kFilterConservative = 1, // fused, widened test: superset of the exact candidates
+    kFilterNoResolve = 2     // timing diagnostic (wrong images): phase 1 only
+};
+
 struct TraceArgs {
-    const Geom *geom;          // n records, padded with zeros to a multiple of kBlock
+    const Geom *geom;          // n records for `filter`, padded with zeros to a multiple of kBlock
+    const float *r2;           // exact squared radii, same padding
     const rt_sphere *spheres;  // n records, the caller's list
     uint32_t n;
+    int32_t filter;
     uint32_t tile_cap;         // spheres per LDS tile, multiple of kBlock
     rt_camera cam;
     uint32_t width, height;
@@ -36,7 +46,7 @@ struct TraceArgs {
     uint32_t tiles_x, tiles_y; // 8x8 tiles of the region
     uint32_t tile_first, tile_stride, n_chunks; // chunk c traces tile tile_first + c*tile_stride
     uint32_t *sums;            // full frame uint32 x3
-    unsigned long long *rays;  // ray counter
+    unsigned long long *rays;  // [0] ray counter, [1] wave passes over the sphere list
     uint32_t *chunk_counter;   // work queue head, zeroed before launch
 };
 
@@ -49,6 +59,8 @@ struct ResolveArgs {
 
 struct HitsArgs {
     const Geom *geom;
+    const float *r2;
+    int32_t conservative;
     uint32_t n;
     rt_camera cam;
     uint32_t width, height;
@@ -57,6 +69,8 @@ struct HitsArgs {
 
 struct IntersectArgs {
     const Geom *geom;
+    const float *r2;
+    int32_t conservative;
     const rt_sphere *spheres;
     uint32_t n;
     const float *rays;

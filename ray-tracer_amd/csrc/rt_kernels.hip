@@ -9,10 +9,14 @@
 //     never idle on short paths while long ones finish;
 //   * the sphere list is streamed through LDS in tiles of {cx, cy, cz, r*r};
 //     every lane reads the same record (LDS broadcast, conflict free);
-//   * the hot loop only decides `discriminant < 0` per sphere and shifts the
-//     answer into a per-lane 32-bit candidate mask -- no branch, no sqrt, no
-//     divide.  Candidates (a handful per ray) are then resolved in list order
-//     with the reference's exact root selection;
+//   * the hot loop only decides, per sphere, whether the reference's
+//     `discriminant < 0` early-out CAN fail, and shifts the answer into a
+//     per-lane 32-bit candidate mask -- no branch, no sqrt, no divide.  It uses
+//     a conservative test evaluated with fused multiply-adds (12 instructions
+//     per sphere): it may flag a sphere the reference rejects, never the
+//     reverse (bound below, at filter_sign).  Candidates (a handful per ray) are
+//     then resolved in list order with the reference's exact, unfused
+//     arithmetic and root selection, so results are bit-identical;
 //   * colour is byte-quantised at every recursion level in the reference, so
 //     the iterative path records the spheres it bounced off in an LDS stack and
 //     replays the per-level byte arithmetic in reverse once it terminates;
@@ -97,13 +101,26 @@ __device__ __forceinline__ void sky(float dy, int &r, int &g, int &b)
 struct RayState {
     float ox, oy, oz, dx, dy, dz;
     float four_a, two_a; // 4*dot(D,D), 2*dot(D,D)
+    float a_filter;      // dot(D,D) * (1 - 2^-17), the conservative filter's A
+    bool tame;           // all components finite and small enough for the filter's bound
 };
+
+// Magnitude limits under which the conservative filter's arithmetic can neither
+// overflow nor lose its margin to underflow (see filter_sign).
+constexpr float kTameMax = 0x1p29f;  // |coordinate|, |direction component|
+constexpr float kTameMinA = 0x1p-60f; // dot(D,D)
 
 __device__ __forceinline__ void ray_prepare(RayState &r)
 {
     const float A = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz; // dot(): products summed left to right
     r.four_a = 4.0f * A;
     r.two_a = 2.0f * A;
+    r.a_filter = __builtin_fmaf(-0x1p-17f, A, A);
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fmaxf(fabsf(r.oz), fabsf(r.dx))),
+                          fmaxf(fabsf(r.dy), fabsf(r.dz)));
+    // comparisons are false for NaN, so a NaN anywhere makes the ray not tame
+    r.tame = (m < kTameMax) && (A >= kTameMinA) && (r.ox == r.ox) && (r.oy == r.oy) && (r.oz == r.oz) &&
+             (r.dx == r.dx) && (r.dy == r.dy) && (r.dz == r.dz);
 }
 
 // Camera::GetRay, Source/main.cpp:440-444, for pixel (i, j) with jitter (ju, jv)
@@ -154,29 +171,75 @@ __device__ __forceinline__ bool resolve_candidate(const RayState &r, const Geom 
     return true;
 }
 
+// Conservative form of the `Discriminant < 0` early-out, Source/main.cpp:481.
+//
+// Returns a float whose SIGN BIT is set only if the reference's test certainly
+// rejects the sphere.  With oc = O - C (the same three rounded subtractions as
+// the reference), d* = oc.D, q* = oc.oc and A = fl(D.D) as exact real numbers,
+// the reference takes the hit branch only if
+//     d*^2 - A (q* - r^2)  >=  -u A (12.4 q* + 2.1 r^2),      u = 2^-24,
+// (its 3-term dot products carry a relative error of at most 3u on the sum of
+// absolute terms, |d*| <= sqrt(A_true q*), and each of B*B, 4A*C, q - r^2 adds
+// one rounding).  The filter evaluates
+//     s = d~^2 - A(1 - 2^-17) (q~ - r^2 (1 + 2^-16))
+// with fused chains whose errors are bounded the same way, which gives
+//     s >= [d*^2 - A (q* - r^2)] + u A (128 q* + 63.9 r^2) - u A (10.4 q* + 4.2 r^2),
+// so whenever the reference accepts, s >= u A (105 q* + 57 r^2) > 0: no false
+// reject.  False accepts (relative width 1e-5) only cost one exact evaluation.
+// Preconditions, checked per ray (RayState::tame) and per scene (host side):
+// every magnitude below 2^29 (no overflow: all intermediates stay under 2^127)
+// and A, r^2 >= 2^-60 (the margin exceeds any underflow loss by > 10^20).
+// Rays or scenes outside them take every sphere as a candidate.
+__device__ __forceinline__ float filter_sign(const RayState &r, const Geom &s)
+{
+    const float ocx = r.ox - s.cx, ocy = r.oy - s.cy, ocz = r.oz - s.cz;
+    const float d = __builtin_fmaf(ocz, r.dz, __builtin_fmaf(ocy, r.dy, ocx * r.dx));
+    // s.r2 holds r^2 (1 + 2^-16) in the filter's copy of the geometry
+    const float c = __builtin_fmaf(ocx, ocx, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocz, ocz, -s.r2)));
+    return __builtin_fmaf(d, d, -(r.a_filter * c));
+}
+
 // IntersectSceneSpheres over one LDS tile (Source/main.cpp:534-546).  `tile`
-// holds `count` spheres padded to a multiple of kBlock; `base` is the list
-// index of tile[0].  Phase 1 (uniform, branch free): 32 discriminant signs per
-// mask word.  Phase 2 (divergent, rare): candidates in list order.
-__device__ __forceinline__ void scan_tile(const Geom *__restrict__ tile, uint32_t count,
-                                          uint32_t base, const RayState &r, float tmin,
+// holds `count` spheres padded to a multiple of kBlock and `r2` their exact
+// squared radii; `base` is the list index of tile[0].  Phase 1 (uniform, branch
+// free): 32 early-out decisions per mask word.  Phase 2 (divergent, rare):
+// candidates in list order with the reference's arithmetic.
+template <int FILTER>
+__device__ __forceinline__ void scan_tile(const Geom *__restrict__ tile, const float *__restrict__ r2,
+                                          uint32_t count, uint32_t base, const RayState &r, float tmin,
                                           float &closest, int &best)
 {
     for (uint32_t b = 0; b < count; b += kBlock) {
         uint32_t mask = 0u;
+        if (FILTER == kFilterExact) {
 #pragma unroll
-        for (int j = 0; j < kBlock; ++j) {
-            float B;
-            const float disc = discriminant(r, tile[b + j], B);
-            // the reference takes the hit branch unless disc < 0 (so also for NaN)
-            mask = (mask << 1) | (disc < 0.0f ? 0u : 1u);
+            for (int j = 0; j < kBlock; ++j) {
+                float B;
+                Geom s = tile[b + j];
+                s.r2 = r2[b + j];
+                const float disc = discriminant(r, s, B);
+                // the reference takes the hit branch unless disc < 0 (so also for NaN)
+                mask = (mask << 1) | (disc < 0.0f ? 0u : 1u);
+            }
+        } else {
+            uint32_t reject = 0u;
+#pragma unroll
+            for (int j = 0; j < kBlock; ++j) // shift the sign bit in from the right
+                reject = __builtin_amdgcn_alignbit(reject, __float_as_uint(filter_sign(r, tile[b + j])), 31);
+            mask = r.tame ? ~reject : 0xFFFFFFFFu;
         }
         if (b + kBlock > count) // padding records of the last block
             mask &= ~(0xFFFFFFFFu >> (count - b));
+        if (FILTER == kFilterNoResolve) { // timing diagnostic only: keeps phase 1 alive, skips phase 2
+            best ^= (int)mask;
+            continue;
+        }
         while (mask) {
             const int j = __clz((int)mask);
             mask &= ~(0x80000000u >> j);
-            if (resolve_candidate(r, tile[b + j], tmin, closest))
+            Geom s = tile[b + j];
+            s.r2 = r2[b + j];
+            if (resolve_candidate(r, s, tmin, closest))
                 best = (int)(base + b + j);
         }
     }
@@ -216,14 +279,17 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Copies spheres [t0, t0+cnt) of the padded geometry list into the LDS tile.
-__device__ __forceinline__ void load_tile(Geom *tile, const Geom *__restrict__ geom, uint32_t t0,
-                                          uint32_t cnt_padded)
+// Copies spheres [t0, t0+cnt) of the padded geometry list and of the exact
+// squared radii into the LDS tile.
+__device__ __forceinline__ void load_tile(Geom *tile, float *tile_r2, const Geom *__restrict__ geom,
+                                          const float *__restrict__ r2, uint32_t t0, uint32_t cnt_padded)
 {
     const float4 *src = reinterpret_cast<const float4 *>(geom + t0);
     float4 *dst = reinterpret_cast<float4 *>(tile);
-    for (uint32_t i = threadIdx.x; i < cnt_padded; i += blockDim.x)
+    for (uint32_t i = threadIdx.x; i < cnt_padded; i += blockDim.x) {
         dst[i] = src[i];
+        tile_r2[i] = r2[t0 + i];
+    }
 }
 
 __device__ __forceinline__ uint32_t round_up_block(uint32_t n)
@@ -236,12 +302,13 @@ __device__ __forceinline__ uint32_t round_up_block(uint32_t n)
 // (Source/main.cpp:551-598, 613-645), iterative.
 // ---------------------------------------------------------------------------
 
-template <bool MULTI_TILE>
+template <bool MULTI_TILE, int FILTER>
 __global__ void __launch_bounds__(kTraceThreads) trace_kernel(const TraceArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     Geom *tile = reinterpret_cast<Geom *>(smem);
-    uint32_t *stack = reinterpret_cast<uint32_t *>(smem + (size_t)a.tile_cap * sizeof(Geom));
+    float *tile_r2 = reinterpret_cast<float *>(smem + (size_t)a.tile_cap * sizeof(Geom));
+    uint32_t *stack = reinterpret_cast<uint32_t *>(tile_r2 + a.tile_cap);
     const int stack_levels = a.max_depth > 0 ? a.max_depth : 1;
     uint32_t *wave_flags = stack + (size_t)stack_levels * kTraceThreads;
 
@@ -251,7 +318,7 @@ __global__ void __launch_bounds__(kTraceThreads) trace_kernel(const TraceArgs a)
     const uint32_t n_pad = round_up_block(a.n);
 
     if (!MULTI_TILE) {
-        load_tile(tile, a.geom, 0u, n_pad);
+        load_tile(tile, tile_r2, a.geom, a.r2, 0u, n_pad);
         __syncthreads();
     }
 
@@ -266,6 +333,7 @@ __global__ void __launch_bounds__(kTraceThreads) trace_kernel(const TraceArgs a)
     uint32_t pixel = 0u, sample = 0u, call = 0u;
     int depth = 0, level = 0;
     uint32_t n_rays = 0u;
+    uint32_t n_rounds = 0u; // wave-uniform: passes over the sphere list
 
     for (;;) {
         // ---- refill idle lanes from the wave's chunk, pulling new chunks as needed
@@ -338,14 +406,16 @@ __global__ void __launch_bounds__(kTraceThreads) trace_kernel(const TraceArgs a)
             for (uint32_t t0 = 0u; t0 < a.n; t0 += a.tile_cap) {
                 const uint32_t cnt = min(a.tile_cap, a.n - t0);
                 __syncthreads(); // everyone is done with the previous tile (and with wave_flags)
-                load_tile(tile, a.geom, t0, round_up_block(cnt));
+                load_tile(tile, tile_r2, a.geom, a.r2, t0, round_up_block(cnt));
                 __syncthreads();
                 if (active)
-                    scan_tile(tile, cnt, t0, ray, 0.001f, closest, best);
+                    scan_tile<FILTER>(tile, tile_r2, cnt, t0, ray, 0.001f, closest, best);
             }
         } else if (active) {
-            scan_tile(tile, a.n, 0u, ray, 0.001f, closest, best);
+            scan_tile<FILTER>(tile, tile_r2, a.n, 0u, ray, 0.001f, closest, best);
         }
+        if (wave_active)
+            ++n_rounds;
 
         // ---- GetRayColor's branches, Source/main.cpp:562-597
         if (active) {
@@ -416,8 +486,10 @@ __global__ void __launch_bounds__(kTraceThreads) trace_kernel(const TraceArgs a)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
         total += __shfl_down(total, off, 64);
-    if (lane == 0 && total != 0ull)
+    if (lane == 0 && total != 0ull) {
         atomicAdd(a.rays, total);
+        atomicAdd(a.rays + 1, (unsigned long long)n_rounds);
+    }
 }
 
 // FinalColor / SPP, ToRGB(ivec3), PutPixel -- Source/main.cpp:638-642.
@@ -442,6 +514,7 @@ __global__ void __launch_bounds__(256) primary_hits_kernel(const HitsArgs a, uin
 {
     extern __shared__ __align__(16) unsigned char smem[];
     Geom *tile = reinterpret_cast<Geom *>(smem);
+    float *tile_r2 = reinterpret_cast<float *>(smem + (size_t)tile_cap * sizeof(Geom));
 
     // 64x4 pixel footprint per workgroup
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
@@ -457,10 +530,14 @@ __global__ void __launch_bounds__(256) primary_hits_kernel(const HitsArgs a, uin
     for (uint32_t t0 = 0u; t0 < a.n; t0 += tile_cap) {
         const uint32_t cnt = min(tile_cap, a.n - t0);
         __syncthreads();
-        load_tile(tile, a.geom, t0, round_up_block(cnt));
+        load_tile(tile, tile_r2, a.geom, a.r2, t0, round_up_block(cnt));
         __syncthreads();
-        if (inside)
-            scan_tile(tile, cnt, t0, ray, 0.001f, closest, best);
+        if (inside) {
+            if (a.conservative)
+                scan_tile<kFilterConservative>(tile, tile_r2, cnt, t0, ray, 0.001f, closest, best);
+            else
+                scan_tile<kFilterExact>(tile, tile_r2, cnt, t0, ray, 0.001f, closest, best);
+        }
     }
     if (inside)
         a.hits[(size_t)px + (size_t)py * a.width] = best;
@@ -471,6 +548,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, u
 {
     extern __shared__ __align__(16) unsigned char smem[];
     Geom *tile = reinterpret_cast<Geom *>(smem);
+    float *tile_r2 = reinterpret_cast<float *>(smem + (size_t)tile_cap * sizeof(Geom));
 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool inside = i < a.n_rays;
@@ -486,10 +564,14 @@ __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, u
     for (uint32_t t0 = 0u; t0 < a.n; t0 += tile_cap) {
         const uint32_t cnt = min(tile_cap, a.n - t0);
         __syncthreads();
-        load_tile(tile, a.geom, t0, round_up_block(cnt));
+        load_tile(tile, tile_r2, a.geom, a.r2, t0, round_up_block(cnt));
         __syncthreads();
-        if (inside)
-            scan_tile(tile, cnt, t0, ray, 0.001f, closest, best);
+        if (inside) {
+            if (a.conservative)
+                scan_tile<kFilterConservative>(tile, tile_r2, cnt, t0, ray, 0.001f, closest, best);
+            else
+                scan_tile<kFilterExact>(tile, tile_r2, cnt, t0, ray, 0.001f, closest, best);
+        }
     }
     if (!inside)
         return;
@@ -520,7 +602,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, u
 size_t trace_lds_bytes(uint32_t tile_cap, int32_t max_depth)
 {
     const size_t levels = max_depth > 0 ? (size_t)max_depth : 1u;
-    return (size_t)tile_cap * sizeof(Geom) + levels * kTraceThreads * sizeof(uint32_t) +
+    return (size_t)tile_cap * (sizeof(Geom) + sizeof(float)) + levels * kTraceThreads * sizeof(uint32_t) +
            4u * sizeof(uint32_t);
 }
 
@@ -528,17 +610,35 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
 {
     const size_t lds = trace_lds_bytes(a.tile_cap, a.max_depth);
     const bool multi = a.n > a.tile_cap;
-    if (multi)
-        hipLaunchKernelGGL(trace_kernel<true>, dim3(n_workgroups), dim3(kTraceThreads), lds, stream, a);
-    else
-        hipLaunchKernelGGL(trace_kernel<false>, dim3(n_workgroups), dim3(kTraceThreads), lds, stream, a);
+    const dim3 grid(n_workgroups), block(kTraceThreads);
+    switch (a.filter) {
+    case kFilterExact:
+        if (multi)
+            hipLaunchKernelGGL((trace_kernel<true, kFilterExact>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((trace_kernel<false, kFilterExact>), grid, block, lds, stream, a);
+        break;
+    case kFilterConservative:
+        if (multi)
+            hipLaunchKernelGGL((trace_kernel<true, kFilterConservative>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((trace_kernel<false, kFilterConservative>), grid, block, lds, stream, a);
+        break;
+#ifdef RT_DIAGNOSTIC_KERNELS
+    case kFilterNoResolve:
+        hipLaunchKernelGGL((trace_kernel<false, kFilterNoResolve>), grid, block, lds, stream, a);
+        break;
+#endif
+    default:
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
 hipError_t trace_occupancy(size_t lds_bytes, int *workgroups_per_cu)
 {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(workgroups_per_cu, trace_kernel<false>,
-                                                        kTraceThreads, lds_bytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        workgroups_per_cu, trace_kernel<false, kFilterConservative>, kTraceThreads, lds_bytes);
 }
 
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream)
@@ -563,7 +663,8 @@ hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream)
         return hipSuccess;
     const uint32_t cap = scan_tile_cap(a.n);
     dim3 grid((a.width + 63u) / 64u, (a.height + 3u) / 4u);
-    hipLaunchKernelGGL(primary_hits_kernel, grid, dim3(256), (size_t)cap * sizeof(Geom), stream, a, cap);
+    hipLaunchKernelGGL(primary_hits_kernel, grid, dim3(256), (size_t)cap * (sizeof(Geom) + sizeof(float)), stream,
+                       a, cap);
     return hipGetLastError();
 }
 
@@ -573,7 +674,7 @@ hipError_t launch_intersect(const IntersectArgs &a, hipStream_t stream)
         return hipSuccess;
     const uint32_t cap = scan_tile_cap(a.n);
     hipLaunchKernelGGL(intersect_kernel, dim3((a.n_rays + 255u) / 256u), dim3(256),
-                       (size_t)cap * sizeof(Geom), stream, a, cap);
+                       (size_t)cap * (sizeof(Geom) + sizeof(float)), stream, a, cap);
     return hipGetLastError();
 }
 

@@ -18,12 +18,14 @@ SPHERE_DTYPE = np.dtype(
 assert SPHERE_DTYPE.itemsize == 36
 
 MAT_GLASS, MAT_DIFFUSE, MAT_METAL, MAT_FUZZYMETAL = 0, 1, 2, 3
+OPT_FILTER, OPT_TILE_SPHERES, OPT_WORKGROUPS_PER_CU = 0, 1, 2
+FILTER_EXACT, FILTER_CONSERVATIVE = 0, 1
 
 # every symbol include/rt_mi355x.h declares
 EXPORTS = [
     "rt_abi_version", "rt_status_string", "rt_last_error", "rt_create", "rt_destroy", "rt_set_scene",
     "rt_camera_init", "rt_render", "rt_render_device", "rt_accumulate_device", "rt_resolve_device",
-    "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_get_stats", "rt_reset_stats",
+    "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_get_stats", "rt_reset_stats",
 ]
 
 
@@ -54,6 +56,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("rays", C.c_uint64),
         ("sphere_tests", C.c_uint64),
+        ("wave_passes", C.c_uint64),
         ("last_kernel_ms", C.c_double),
         ("last_wall_ms", C.c_double),
     ]
@@ -92,6 +95,7 @@ def load():
     L.rt_primary_hits.argtypes = [vp, C.POINTER(Camera), u32, u32, vp]
     L.rt_primary_hits_device.argtypes = [vp, C.POINTER(Camera), u32, u32, vp, vp]
     L.rt_intersect.argtypes = [vp, vp, u32, vp]
+    L.rt_set_option.argtypes = [vp, i, C.c_int64]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_reset_stats.argtypes = [vp]
     _lib = L
@@ -196,6 +200,9 @@ class Context:
         out = np.zeros(len(rays), dtype=np.dtype([("index", "<i4"), ("t", "<f4"), ("point", "<f4", 3), ("normal", "<f4", 3)]))
         self._check(self._L.rt_intersect(self._h, rays.ctypes.data, len(rays), out.ctypes.data))
         return out
+
+    def set_option(self, option, value):
+        self._check(self._L.rt_set_option(self._h, option, value))
 
     def stats(self):
         s = Stats()

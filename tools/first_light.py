@@ -36,17 +36,25 @@ img = ctx.render(ccam, p)
 ref, _, rays = O.trace_tile(c3, occam, 96, 54, 4, 8, O.RNG_COUNTER, seed=1)
 print("c3 96x54x4 equal:", (img == ref).all(), "mismatch px:", int((img != ref).any(axis=2).sum()), "rays gpu", ctx.stats().rays, "oracle", rays, flush=True)
 
+# exact vs conservative filter on the same frame
+p = rtamd.params(480, 270, 8, 8, seed=5)
+ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_EXACT); ctx.reset_stats(); a = ctx.render(ccam, p); ra = ctx.stats().rays
+ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_CONSERVATIVE); ctx.reset_stats(); b = ctx.render(ccam, p); rb = ctx.stats().rays
+print("filters agree:", (a == b).all(), ra, rb, flush=True)
+
 # timed C3 frame
 W, H, SPP, D = 1920, 1080, 64, 8
 p = rtamd.params(W, H, SPP, D, seed=1)
 d_rgb = torch.empty(W * H * 3, dtype=torch.uint8, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
-for it in range(3):
+for it in range(6):
+    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_EXACT if it < 2 else rtamd.FILTER_CONSERVATIVE)
     ctx.reset_stats()
     torch.cuda.synchronize()
     t0 = time.time()
     ctx.render_device(ccam, p, d_rgb.data_ptr(), stream=s)
     torch.cuda.synchronize()
     dt = time.time() - t0
-    rays = ctx.stats().rays
+    st = ctx.stats(); rays = st.rays
+    print("lane utilisation %.3f" % (rays / (64.0 * st.wave_passes)), end=" ")
     print(f"C3 frame {dt*1e3:.2f} ms rays {rays} Mrays/s {rays/dt/1e6:.1f} frac_fp32 {rays*500*25/dt/157.3e12:.3f}", flush=True)
