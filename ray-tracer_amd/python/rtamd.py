@@ -74,6 +74,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # A process must hold ONE HIP runtime.  PyTorch wheels bundle their own
+    # libamdhip64; if this library pulled in /opt/rocm's copy first, torch would
+    # later find no device.  So when torch is installed, let it load its runtime
+    # first; librt_mi355x.so then binds to that same copy (equal SONAME).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RtError(f"{LIB_PATH} not built: run `make -C ray-tracer_amd/csrc` (or __graft_entry__.build())")
     L = C.CDLL(LIB_PATH)

@@ -1,0 +1,333 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the
+reference's golden outputs.  Bit-exact for indices, bytes and integer sums;
+PSNR >= 40 dB and mean absolute error <= 1.0 (8-bit) against converged reference
+images, where the random streams differ by construction."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle_lib as O
+import rtamd
+import scenes
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KAT = json.load(open(os.path.join(G, "kat.json")))
+C3_CAM = scenes.RANDOM_SPHERES_CAMERA
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = rtamd.Context(0)
+    yield c
+    c.close()
+
+
+def c3_scene():
+    return np.fromfile(os.path.join(G, "scene_c3_500.bin"), dtype=rtamd.SPHERE_DTYPE)
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 10 * np.log10(255.0 ** 2 / mse) if mse > 0 else float("inf")
+
+
+# ---------------------------------------------------------------- deterministic primary rays
+
+
+def test_primary_hits_default_scene_matches_reference_map(ctx):
+    ctx.set_scene(rtamd.default_scene())
+    got = ctx.primary_hits(rtamd.default_camera(), 1920, 1080)
+    want = np.load(os.path.join(G, "c2_default_hits.npz"))["hits"]
+    assert np.array_equal(got, want)
+    assert "%016x" % O.fnv1a64(got) == KAT["c2_default_fnv"]
+
+
+@pytest.mark.parametrize("filt", [rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE])
+def test_primary_hits_random_spheres_matches_reference_map(ctx, filt):
+    ctx.set_option(rtamd.OPT_FILTER, filt)
+    ctx.set_scene(c3_scene())
+    got = ctx.primary_hits(rtamd.make_camera(*C3_CAM), 1920, 1080)
+    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_CONSERVATIVE)
+    want = np.load(os.path.join(G, "c2_c3scene_hits.npz"))["hits"]
+    assert np.array_equal(got, want)
+
+
+def test_generated_scene_equals_committed_fixture():
+    assert scenes.random_spheres(500).tobytes() == c3_scene().tobytes()
+
+
+@pytest.mark.parametrize("name", ["default", "c3scene"])
+def test_intersect_matches_reference_vectors(ctx, name):
+    z = np.load(os.path.join(G, f"isect_{name}.npz"))
+    ctx.set_scene(rtamd.default_scene() if name == "default" else c3_scene())
+    got = ctx.intersect(z["rays"])
+    assert got.tobytes() == z["out"].tobytes()
+
+
+def test_intersect_ties_inside_tangent_and_degenerate(ctx):
+    """Later sphere wins equal T; origins inside spheres; zero-length and NaN directions."""
+    rs = np.random.RandomState(11)
+    n = 70  # not a multiple of 32: ragged last mask word
+    sc = np.zeros(n, dtype=rtamd.SPHERE_DTYPE)
+    sc["center"] = rs.uniform(-4, 4, size=(n, 3)).astype(np.float32)
+    sc["radius"] = rs.uniform(0.3, 1.5, size=n).astype(np.float32)
+    sc["material"] = 1
+    sc[40] = sc[7]   # exact duplicates: ties
+    sc[69] = sc[7]
+    ctx.set_scene(sc)
+    rays = np.zeros((4096, 6), dtype=np.float32)
+    rays[:, :3] = rs.uniform(-5, 5, size=(4096, 3))
+    rays[:, 3:] = rs.uniform(-1, 1, size=(4096, 3))
+    rays[:64, :3] = sc["center"][:64] + 0.1  # inside
+    rays[64:128, 3:] = sc["center"][7] - rays[64:128, :3]  # aimed at the duplicated sphere
+    rays[128, 3:] = 0.0  # A == 0: NaN root, accepted by the reference's comparisons
+    rays[129, 3:] = (np.nan, 1.0, 0.0)
+    rays[130, :3] = (np.inf, 0.0, 0.0)
+    rays[131, 3:] = (1e30, 1e30, 1e30)
+    rays[132, 3:] = (1e-30, 0.0, 0.0)
+    got = ctx.intersect(rays)
+    t, p, nrm = C.c_float(), (C.c_float * 3)(), (C.c_float * 3)()
+    ties = 0
+    for i, r in enumerate(rays):
+        idx = O.lib().orc_intersect(sc.ctypes.data, n, (C.c_float * 3)(*r[:3]), (C.c_float * 3)(*r[3:]), 0.001,
+                                    float("inf"), C.byref(t), p, nrm)
+        assert got["index"][i] == idx, (i, r)
+        ties += idx == 69
+        if idx >= 0 and np.isfinite(r).all() and i not in (128, 131, 132):
+            want = np.array([t.value, *p, *nrm], dtype=np.float32)
+            have = np.concatenate([[got["t"][i]], got["point"][i], got["normal"][i]]).astype(np.float32)
+            assert want.tobytes() == have.tobytes(), i
+    assert ties >= 5 and not np.isin(got["index"], [7, 40]).any()  # only the LAST copy of the duplicated sphere ever wins
+
+
+def test_primary_hits_untamed_scene_falls_back_to_exact_scan(ctx):
+    """A zero-radius and a huge sphere violate the filter's preconditions."""
+    sc = rtamd.default_scene()
+    sc = np.concatenate([sc, sc[:2]])
+    sc[4]["radius"] = 0.0
+    sc[5]["center"] = (1e12, 0, 0)
+    ctx.set_scene(sc)
+    got = ctx.primary_hits(rtamd.default_camera(), 320, 180)
+    assert np.array_equal(got, O.primary_hits(sc, O.default_camera(), 320, 180))
+
+
+# ---------------------------------------------------------------- stochastic frames, bit-exact vs oracle
+
+
+@pytest.mark.parametrize(
+    "scene,cam,W,H,spp,depth,seed",
+    [
+        ("default", scenes.DEFAULT_CAMERA, 128, 72, 8, 10, 7),
+        ("default", scenes.DEFAULT_CAMERA, 37, 23, 5, 3, 1),  # ragged: partial 8x8 tiles
+        ("default", ((-2.0, 2.0, 1.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 90.0), 64, 36, 4, 10, 2),  # commented camera, :600-603
+        ("c3", C3_CAM, 96, 54, 4, 8, 1),
+        ("c3", C3_CAM, 40, 30, 2, 1, 99),  # depth 1: primary rays only
+    ],
+)
+def test_frame_bit_exact_against_oracle(ctx, scene, cam, W, H, spp, depth, seed):
+    sc = rtamd.default_scene() if scene == "default" else c3_scene()
+    ctx.set_scene(sc)
+    ctx.reset_stats()
+    got = ctx.render(rtamd.make_camera(*cam), rtamd.params(W, H, spp, depth, seed=seed))
+    want, _, rays = O.trace_tile(sc, O.camera(*cam), W, H, spp, depth, O.RNG_COUNTER, seed=seed)
+    assert np.array_equal(got, want)
+    assert ctx.stats().rays == rays
+
+
+def test_multi_tile_sphere_list_bit_exact(ctx):
+    """Sphere list longer than one LDS tile: 3 tiles of 64 plus a ragged one."""
+    sc = scenes.random_spheres(230, grid_half=8, seed=3)
+    cam = C3_CAM
+    ctx.set_option(rtamd.OPT_TILE_SPHERES, 64)
+    try:
+        ctx.set_scene(sc)
+        ctx.reset_stats()
+        got = ctx.render(rtamd.make_camera(*cam), rtamd.params(64, 36, 3, 6, seed=4))
+        rays_gpu = ctx.stats().rays
+        hits = ctx.primary_hits(rtamd.make_camera(*cam), 160, 90)
+    finally:
+        ctx.set_option(rtamd.OPT_TILE_SPHERES, 2048)
+    want, _, rays = O.trace_tile(sc, O.camera(*cam), 64, 36, 3, 6, O.RNG_COUNTER, seed=4)
+    assert np.array_equal(got, want) and rays_gpu == rays
+    assert np.array_equal(hits, O.primary_hits(sc, O.camera(*cam), 160, 90))
+
+
+def test_exact_and_conservative_scans_agree(ctx):
+    ctx.set_scene(c3_scene())
+    cam, p = rtamd.make_camera(*C3_CAM), rtamd.params(480, 270, 8, 8, seed=5)
+    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_EXACT)
+    a = ctx.render(cam, p)
+    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_CONSERVATIVE)
+    b = ctx.render(cam, p)
+    assert np.array_equal(a, b)
+
+
+def test_sub_tile_leaves_rest_of_frame_untouched(ctx):
+    """TraceThreadFunction(xstart, ystart, xsize, ysize) on a strip, like TraceScene's four."""
+    sc = rtamd.default_scene()
+    ctx.set_scene(sc)
+    W, H = 64, 36
+    p = rtamd.params(W, H, 4, 10, seed=3)
+    cam = rtamd.default_camera()
+    full = ctx.render(cam, p)
+    img = np.full((H, W, 3), 255, dtype=np.uint8)  # g_PixelData's memset, Source/main.cpp:175
+    ctx.render(cam, p, tile=(16, 0, 16, H), rgb=img)
+    assert np.array_equal(img[:, 16:32], full[:, 16:32])
+    assert (img[:, :16] == 255).all() and (img[:, 32:] == 255).all()
+    # four strips assemble the frame; out-of-range parts are dropped like PutPixel does
+    for t in range(4):
+        ctx.render(cam, p, tile=(16 * t, -5, 16, H + 20), rgb=img)
+    assert np.array_equal(img, full)
+
+
+def test_sample_slices_and_interleaved_tiles_are_partition_invariant(ctx, torch):
+    sc = c3_scene()
+    ctx.set_scene(sc)
+    cam = rtamd.make_camera(*C3_CAM)
+    W, H, SPP, D = 100, 60, 6, 8
+    want, sums_o, rays_o = O.trace_tile(sc, O.camera(*C3_CAM), W, H, SPP, D, O.RNG_COUNTER, seed=8, want_sums=True)
+    # (a) one call
+    d_sums = torch.zeros(H * W * 3, dtype=torch.int32, device="cuda")
+    ctx.reset_stats()
+    ctx.accumulate_device(cam, rtamd.params(W, H, SPP, D, seed=8), d_sums.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_sums.cpu().numpy().view(np.uint32).reshape(H, W, 3), sums_o)
+    assert ctx.stats().rays == rays_o
+    # (b) 2 sample slices x 3 interleaved tile sets, as 6 "ranks"
+    d_sums.zero_()
+    ctx.reset_stats()
+    for s0, sc_ in ((0, 4), (4, 2)):
+        for first in range(3):
+            p = rtamd.params(W, H, SPP, D, seed=8, sample_begin=s0, sample_count=sc_, tile_first=first, tile_stride=3)
+            ctx.accumulate_device(cam, p, d_sums.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_sums.cpu().numpy().view(np.uint32).reshape(H, W, 3), sums_o)
+    assert ctx.stats().rays == rays_o
+    d_rgb = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+    ctx.resolve_device(d_sums.data_ptr(), W, H, SPP, d_rgb.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_rgb.cpu().numpy().reshape(H, W, 3), want)
+
+
+def test_edge_cases(ctx):
+    cam = rtamd.default_camera()
+    # empty scene: every ray is sky
+    ctx.set_scene(np.zeros(0, dtype=rtamd.SPHERE_DTYPE))
+    got = ctx.render(cam, rtamd.params(33, 17, 2, 5, seed=1))
+    want, _, _ = O.trace_tile(np.zeros(0, dtype=O.SPHERE_DTYPE), O.default_camera(), 33, 17, 2, 5, O.RNG_COUNTER, seed=1)
+    assert np.array_equal(got, want)
+    assert (ctx.primary_hits(cam, 33, 17) == -1).all()
+    # depth 0: GetRayColor returns black without tracing
+    ctx.set_scene(rtamd.default_scene())
+    ctx.reset_stats()
+    assert (ctx.render(cam, rtamd.params(16, 9, 3, 0)) == 0).all()
+    assert ctx.stats().rays == 0
+    # 1x1 frame, 1 sample
+    got = ctx.render(cam, rtamd.params(1, 1, 1, 10, seed=2))
+    want, _, _ = O.trace_tile(O.default_scene(), O.default_camera(), 1, 1, 1, 10, O.RNG_COUNTER, seed=2)
+    assert np.array_equal(got, want)
+    # all four materials incl. Glass / FuzzyMetal (flat white, Source/main.cpp:594)
+    sc = rtamd.default_scene()
+    sc[0]["material"] = rtamd.MAT_GLASS
+    sc[2]["material"] = rtamd.MAT_FUZZYMETAL
+    ctx.set_scene(sc)
+    got = ctx.render(cam, rtamd.params(64, 36, 4, 10, seed=6))
+    want, _, _ = O.trace_tile(sc, O.default_camera(), 64, 36, 4, 10, O.RNG_COUNTER, seed=6)
+    assert np.array_equal(got, want)
+    assert (got[18, 10] == 255).all()  # the glass sphere is flat white
+
+
+def test_error_paths(ctx):
+    fresh = rtamd.Context(0)
+    cam, p = rtamd.default_camera(), rtamd.params(8, 8, 1, 1)
+    buf = np.zeros((8, 8, 3), dtype=np.uint8)
+    assert fresh.call("rt_render", C.byref(cam), C.byref(p), 0, 0, 8, 8, buf.ctypes.data) == -4  # no scene
+    fresh.set_scene(rtamd.default_scene())
+    assert fresh.call("rt_render", None, C.byref(p), 0, 0, 8, 8, buf.ctypes.data) == -1
+    assert fresh.call("rt_render", C.byref(cam), C.byref(p), 0, 0, 8, 8, None) == -1
+    bad = rtamd.params(0, 8, 1, 1)
+    assert fresh.call("rt_render", C.byref(cam), C.byref(bad), 0, 0, 8, 8, buf.ctypes.data) == -1
+    bad = rtamd.params(8, 8, 4, 1, sample_begin=3, sample_count=2)
+    assert fresh.call("rt_render", C.byref(cam), C.byref(bad), 0, 0, 8, 8, buf.ctypes.data) == -1
+    assert b"sample range" in rtamd.load().rt_last_error(fresh._h)
+    assert fresh.call("rt_set_option", 99, 0) == -1
+    fresh.close()
+
+
+# ---------------------------------------------------------------- statistical parity with the reference
+
+
+def test_converged_default_scene_vs_reference_image(ctx):
+    """Reference: 256x144, 4096 spp, depth 10, its own mt19937 stream."""
+    want = np.load(os.path.join(G, "c1_converged_256x144_spp4096_d10.npy"))
+    ctx.set_scene(rtamd.default_scene())
+    got = ctx.render(rtamd.default_camera(), rtamd.params(256, 144, 4096, 10, seed=2024))
+    mae = np.abs(got.astype(int) - want.astype(int)).mean()
+    assert psnr(got, want) >= 40.0, psnr(got, want)
+    assert mae <= 1.0, mae
+
+
+def test_converged_random_spheres_vs_reference_image(ctx):
+    """Reference: 128x72, 1024 spp, depth 8 (noisier than the GPU's 16384 spp estimate)."""
+    want = np.load(os.path.join(G, "c3_converged_128x72_spp1024_d8.npy"))
+    ctx.set_scene(c3_scene())
+    got = ctx.render(rtamd.make_camera(*C3_CAM), rtamd.params(128, 72, 16384, 8, seed=77))
+    mae = np.abs(got.astype(int) - want.astype(int)).mean()
+    assert psnr(got, want) >= 40.0, psnr(got, want)
+    assert mae <= 1.0, mae
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE configs)
+
+
+def test_full_size_frame_properties(ctx, torch):
+    """1920x1080, 64 spp, depth 8, 500 spheres: determinism, partition invariance, sampled oracle pixels."""
+    sc = c3_scene()
+    ctx.set_scene(sc)
+    cam = rtamd.make_camera(*C3_CAM)
+    W, H, SPP, D = 1920, 1080, 64, 8
+    n = W * H * 3
+    a = torch.zeros(n, dtype=torch.int32, device="cuda")
+    b = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx.reset_stats()
+    ctx.accumulate_device(cam, rtamd.params(W, H, SPP, D, seed=1), a.data_ptr())
+    torch.cuda.synchronize()
+    rays_full = ctx.stats().rays
+    # 4 sample slices, each over 2 interleaved tile sets
+    ctx.reset_stats()
+    for k in range(4):
+        for first in range(2):
+            p = rtamd.params(W, H, SPP, D, seed=1, sample_begin=16 * k, sample_count=16, tile_first=first, tile_stride=2)
+            ctx.accumulate_device(cam, p, b.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert ctx.stats().rays == rays_full
+    assert int(a.max()) <= 255 * SPP and int(a.min()) >= 0
+    # checksum of sums is reproducible run to run
+    b.zero_()
+    ctx.accumulate_device(cam, rtamd.params(W, H, SPP, D, seed=1), b.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    # 48 scattered pixels against the oracle, all 64 samples each
+    sums = a.cpu().numpy().view(np.uint32).reshape(H, W, 3)
+    rs = np.random.RandomState(0)
+    ocam = O.camera(*C3_CAM)
+    for x, y in zip(rs.randint(0, W, 48), rs.randint(0, H, 48)):
+        acc = np.zeros(3, dtype=np.int64)
+        for s in range(SPP):
+            rgb, _ = O.sample_color(sc, ocam, W, H, D, 1, int(x), int(y), s)
+            acc += rgb
+        assert sums[y, x].tolist() == acc.tolist(), (x, y)
