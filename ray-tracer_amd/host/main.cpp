@@ -1,0 +1,89 @@
+// main.cpp -- the reference's program (Source/main.cpp:668-679) without the
+// window: set up the scene and camera, trace the frame on the GPU through
+// TraceScene(), write the picture to a PPM file.
+//
+//   rt_render_cli [--width W --height H --spp N --depth D --seed S]
+//                 [--scene spheres.bin] [--camera fx fy fz ax ay az ux uy uz fov]
+//                 [--out image.ppm]
+// Defaults are the reference's shipped constants: 1024x576, 100 spp, depth 10,
+// its four spheres and its camera.
+#include "RayTracerHost.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+namespace RayTracer {
+
+bool WritePPM(const std::string &path, const RenderState &s)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    f << "P6\n" << s.Width << " " << s.Height << "\n255\n";
+    for (unsigned y = 0; y < s.Height; ++y) {
+        const size_t row = (size_t)(s.Height - 1 - y) * s.Width * 3;
+        f.write(reinterpret_cast<const char *>(s.PixelData.data() + row), (std::streamsize)s.Width * 3);
+    }
+    return (bool)f;
+}
+
+} // namespace RayTracer
+
+using namespace RayTracer;
+
+int main(int argc, char **argv)
+{
+    RenderState state;
+    std::string out = "render.ppm";
+    try {
+        for (int i = 1; i < argc; ++i) {
+            const std::string a = argv[i];
+            auto need = [&](int n) { if (i + n >= argc) throw std::invalid_argument("missing value for " + a); };
+            if (a == "--width") { need(1); state.Width = (unsigned)std::atoi(argv[++i]); }
+            else if (a == "--height") { need(1); state.Height = (unsigned)std::atoi(argv[++i]); }
+            else if (a == "--spp") { need(1); state.SPP = std::atoi(argv[++i]); }
+            else if (a == "--depth") { need(1); state.RAY_DEPTH = std::atoi(argv[++i]); }
+            else if (a == "--seed") { need(1); state.Seed = std::strtoull(argv[++i], nullptr, 0); }
+            else if (a == "--out") { need(1); out = argv[++i]; }
+            else if (a == "--scene") {
+                need(1);
+                std::ifstream f(argv[++i], std::ios::binary | std::ios::ate);
+                if (!f) throw std::invalid_argument("cannot open scene file");
+                const std::streamsize bytes = f.tellg();
+                f.seekg(0);
+                state.Spheres.assign((size_t)bytes / sizeof(Sphere), Sphere());
+                f.read(reinterpret_cast<char *>(state.Spheres.data()), bytes);
+            } else if (a == "--camera") {
+                need(10);
+                float v[10];
+                for (float &x : v) x = std::strtof(argv[++i], nullptr);
+                state.SceneCamera = Camera(vec3(v[0], v[1], v[2]), vec3(v[3], v[4], v[5]), vec3(v[6], v[7], v[8]), v[9]);
+            } else {
+                throw std::invalid_argument("unknown option " + a);
+            }
+        }
+
+        DeviceTracer tracer(0);
+        state.AllocatePixels();
+        std::cout << std::endl << "Writing Pixel Data.." << std::endl; // Source/main.cpp:663-664
+        std::cout << "Ray Tracing.." << std::endl;
+        const auto t0 = std::chrono::steady_clock::now();
+        tracer.TraceScene(state);
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const rt_stats st = tracer.Stats();
+        std::printf("%ux%u, %d spp, depth %d, %zu spheres: %llu rays in %.3f s (%.1f Mrays/s, kernels %.3f ms)\n",
+                    state.Width, state.Height, state.SPP, state.RAY_DEPTH, state.Spheres.size(),
+                    (unsigned long long)st.rays, sec, st.rays / sec / 1e6, st.last_kernel_ms);
+        if (!WritePPM(out, state)) {
+            std::fprintf(stderr, "cannot write %s\n", out.c_str());
+            return 2;
+        }
+        std::printf("wrote %s\n", out.c_str());
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
