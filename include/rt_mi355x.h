@@ -158,12 +158,14 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out);
 /* Tuning (no counterpart in the reference) ---------------------------------- */
 
 typedef enum rt_option {
-    /* 1 (default): the sphere scan flags candidates with a fused, conservatively
-     * widened discriminant test and resolves them with the reference's exact
-     * arithmetic; 0: the scan evaluates the reference's unfused discriminant for
-     * every sphere.  Both give bit-identical results; 0 exists to prove it. */
+    /* How the sphere scan finds the spheres that need the reference's exact root
+     * evaluation: 2 (default) a conservatively widened discriminant test as two
+     * 4-term products on the FP32 matrix cores; 1 the same kind of test with fused
+     * multiply-adds on the vector ALU; 0 the reference's own unfused discriminant
+     * for every sphere.  All three give bit-identical results; 0 and 1 exist to
+     * prove it and as fallbacks. */
     RT_OPT_FILTER = 0,
-    RT_OPT_TILE_SPHERES = 1,      /* spheres per LDS tile, 32..8192 (default 2048) */
+    RT_OPT_TILE_SPHERES = 1,      /* spheres per LDS tile, 128..4096 (default 1024) */
     RT_OPT_WORKGROUPS_PER_CU = 2  /* cap on resident workgroups per CU, 0 = occupancy limit */
 } rt_option;
 

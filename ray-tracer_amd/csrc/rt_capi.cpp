@@ -6,6 +6,7 @@
 // the path behind this boundary: without a HIP device every call fails.
 #include "rt_device.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -17,19 +18,23 @@
 
 using namespace rtamd;
 
+// Geometry lists and LDS tiles are padded to whole candidate groups of the matrix scan.
+static constexpr uint32_t kPad = 128;
+
 struct rt_context {
     int device = 0;
     int n_cus = 0;
     hipStream_t stream = nullptr; // used by the synchronous entry points
 
     Geom *d_geom_exact = nullptr;  // {centre, fl(r*r)}
-    Geom *d_geom_filter = nullptr; // {centre, r*r*(1 + 2^-16)}
-    float *d_r2 = nullptr;         // fl(r*r)
+    Geom *d_geom_filter = nullptr; // {centre, r*r*(1 + 2^-16)}: vector-ALU conservative filter
+    Geom *d_geom_matrix = nullptr; // {centre - shift, K}: matrix-core conservative filter
+    float shift[3] = { 0.f, 0.f, 0.f };
     rt_sphere *d_spheres = nullptr;
     uint32_t n_spheres = 0;
     bool have_scene = false;
-    bool scene_tame = false;       // every sphere within the conservative filter's preconditions
-    int filter = kFilterConservative;
+    bool scene_tame = false;       // every sphere within the conservative filters' preconditions
+    int filter = kFilterMatrix;
 
     uint32_t *d_chunk_counter = nullptr;
     unsigned long long *d_rays = nullptr;
@@ -39,7 +44,7 @@ struct rt_context {
     uint8_t *d_rgb = nullptr;   // scratch for rt_render
     size_t rgb_bytes = 0;
 
-    uint32_t tile_cap_max = 2048; // spheres per LDS tile (32 KiB)
+    uint32_t tile_cap_max = 1024; // spheres per LDS tile (2 x 16 B each: 32 KiB)
     int wg_per_cu_override = 0;
 
     double last_kernel_ms = 0.0, last_wall_ms = 0.0;
@@ -131,8 +136,9 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     TraceArgs a;
     memset(&a, 0, sizeof a);
     a.filter = ctx->scene_tame ? ctx->filter : (int)kFilterExact;
-    a.geom = a.filter == kFilterExact ? ctx->d_geom_exact : ctx->d_geom_filter;
-    a.r2 = ctx->d_r2;
+    a.geom = a.filter == kFilterMatrix ? ctx->d_geom_matrix : ctx->d_geom_filter;
+    a.exact = ctx->d_geom_exact;
+    memcpy(a.shift, ctx->shift, sizeof a.shift);
     a.spheres = ctx->d_spheres;
     a.n = ctx->n_spheres;
     a.cam = *cam;
@@ -161,14 +167,14 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     a.chunk_counter = ctx->d_chunk_counter;
 
     // LDS tile: the whole (padded) list when it fits, else tiles of tile_cap_max
-    const uint32_t n_pad = (a.n + (kBlock - 1)) & ~(uint32_t)(kBlock - 1);
-    a.tile_cap = n_pad <= ctx->tile_cap_max ? (n_pad ? n_pad : kBlock) : ctx->tile_cap_max;
+    const uint32_t n_pad = (a.n + (kPad - 1)) & ~(uint32_t)(kPad - 1);
+    a.tile_cap = n_pad <= ctx->tile_cap_max ? (n_pad ? n_pad : kPad) : ctx->tile_cap_max;
 
     const size_t lds = trace_lds_bytes(a.tile_cap, a.max_depth);
     if (lds > 160u * 1024u)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_depth too large for the LDS bounce stack");
     int per_cu = 0;
-    RT_HIP(ctx, trace_occupancy(lds, &per_cu));
+    RT_HIP(ctx, trace_occupancy(a.filter, lds, &per_cu));
     if (per_cu < 1)
         return fail(ctx, RT_ERR_HIP, "trace kernel does not fit on a CU");
     if (ctx->wg_per_cu_override > 0 && ctx->wg_per_cu_override < per_cu)
@@ -247,7 +253,7 @@ int rt_destroy(rt_context *ctx)
     (void)hipDeviceSynchronize();
     if (ctx->d_geom_exact) (void)hipFree(ctx->d_geom_exact);
     if (ctx->d_geom_filter) (void)hipFree(ctx->d_geom_filter);
-    if (ctx->d_r2) (void)hipFree(ctx->d_r2);
+    if (ctx->d_geom_matrix) (void)hipFree(ctx->d_geom_matrix);
     if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
     if (ctx->d_chunk_counter) (void)hipFree(ctx->d_chunk_counter);
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
@@ -270,45 +276,70 @@ int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n)
     RT_HIP(ctx, hipDeviceSynchronize());
     if (ctx->d_geom_exact) { RT_HIP(ctx, hipFree(ctx->d_geom_exact)); ctx->d_geom_exact = nullptr; }
     if (ctx->d_geom_filter) { RT_HIP(ctx, hipFree(ctx->d_geom_filter)); ctx->d_geom_filter = nullptr; }
-    if (ctx->d_r2) { RT_HIP(ctx, hipFree(ctx->d_r2)); ctx->d_r2 = nullptr; }
+    if (ctx->d_geom_matrix) { RT_HIP(ctx, hipFree(ctx->d_geom_matrix)); ctx->d_geom_matrix = nullptr; }
     if (ctx->d_spheres) { RT_HIP(ctx, hipFree(ctx->d_spheres)); ctx->d_spheres = nullptr; }
     ctx->have_scene = false;
 
-    const uint32_t n_pad = (n + (kBlock - 1)) & ~(uint32_t)(kBlock - 1);
-    const size_t cnt = n_pad ? n_pad : kBlock;
-    std::vector<Geom> exact(cnt), filt(cnt);
-    std::vector<float> r2(cnt, 0.0f);
+    const uint32_t n_pad = (n + (kPad - 1)) & ~(uint32_t)(kPad - 1);
+    const size_t cnt = n_pad ? n_pad : kPad;
+    std::vector<Geom> exact(cnt), filt(cnt), matr(cnt);
     memset(exact.data(), 0, cnt * sizeof(Geom));
     memset(filt.data(), 0, cnt * sizeof(Geom));
+
+    // origin of the matrix filter's coordinates: per-axis median of the centres
+    // (robust against a huge, far-away ground sphere)
+    float shift[3] = { 0.f, 0.f, 0.f };
+    if (n) {
+        std::vector<float> axis(n);
+        for (int k = 0; k < 3; ++k) {
+            for (uint32_t i = 0; i < n; ++i) axis[i] = spheres[i].center[k];
+            std::nth_element(axis.begin(), axis.begin() + n / 2, axis.end());
+            shift[k] = std::isfinite(axis[n / 2]) ? axis[n / 2] : 0.f;
+        }
+    }
+
     bool tame = true;
-    for (uint32_t i = 0; i < n; ++i) {
+    for (size_t i = 0; i < cnt; ++i) {
+        if (i >= n) { // padding: never a candidate (K = 1e30 outweighs d^2 for every tame ray)
+            matr[i].cx = matr[i].cy = matr[i].cz = 0.f;
+            matr[i].r2 = 1e30f;
+            continue;
+        }
         const rt_sphere &sp = spheres[i];
         // sphere.Radius * sphere.Radius, Source/main.cpp:478: one rounded product
         volatile float rr = sp.radius * sp.radius;
-        r2[i] = rr;
         exact[i].cx = filt[i].cx = sp.center[0];
         exact[i].cy = filt[i].cy = sp.center[1];
         exact[i].cz = filt[i].cz = sp.center[2];
         exact[i].r2 = rr;
-        // widened radius of the conservative filter, rounded up
+        // widened radius of the conservative filters, rounded up
         volatile float wide = rr + rr * 0x1p-16f;
-        filt[i].r2 = std::nextafter((float)wide, INFINITY);
-        // preconditions of the filter's error bound: magnitudes below 2^29, r*r at least 2^-60
-        const float m = std::fmax(std::fmax(std::fabs(sp.center[0]), std::fabs(sp.center[1])),
-                                  std::fmax(std::fabs(sp.center[2]), std::fabs(sp.radius)));
-        if (!(m < 0x1p29f) || !(rr >= 0x1p-60f))
+        const float r2w = std::nextafter((float)wide, INFINITY);
+        filt[i].r2 = r2w;
+        // matrix filter record: c = fl(C - shift), K = |c|^2 (1 - 2^-18) - r2w (double, rounded once)
+        volatile float cx = sp.center[0] - shift[0], cy = sp.center[1] - shift[1], cz = sp.center[2] - shift[2];
+        const double cc = (double)cx * cx + (double)cy * cy + (double)cz * cz;
+        matr[i].cx = cx; matr[i].cy = cy; matr[i].cz = cz;
+        matr[i].r2 = (float)(cc * (1.0 - 0x1p-18) - (double)r2w);
+        // preconditions of the filters' error bounds: magnitudes below 2^28 (also after the
+        // shift), r*r at least 2^-40
+        const float m = std::fmax(std::fmax(std::fmax(std::fabs(sp.center[0]), std::fabs(sp.center[1])),
+                                            std::fmax(std::fabs(sp.center[2]), std::fabs(sp.radius))),
+                                  std::fmax(std::fmax(std::fabs((float)cx), std::fabs((float)cy)), std::fabs((float)cz)));
+        if (!(m < 0x1p28f) || !(rr >= 0x1p-40f))
             tame = false;
     }
     if (hipMalloc((void **)&ctx->d_geom_exact, cnt * sizeof(Geom)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_geom_filter, cnt * sizeof(Geom)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_r2, cnt * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_geom_matrix, cnt * sizeof(Geom)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_spheres, (size_t)(n ? n : 1) * sizeof(rt_sphere)) != hipSuccess)
         return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for the scene");
     RT_HIP(ctx, hipMemcpy(ctx->d_geom_exact, exact.data(), cnt * sizeof(Geom), hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_geom_filter, filt.data(), cnt * sizeof(Geom), hipMemcpyHostToDevice));
-    RT_HIP(ctx, hipMemcpy(ctx->d_r2, r2.data(), cnt * sizeof(float), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_geom_matrix, matr.data(), cnt * sizeof(Geom), hipMemcpyHostToDevice));
     if (n)
         RT_HIP(ctx, hipMemcpy(ctx->d_spheres, spheres, (size_t)n * sizeof(rt_sphere), hipMemcpyHostToDevice));
+    memcpy(ctx->shift, shift, sizeof shift);
     ctx->scene_tame = tame;
     ctx->n_spheres = n;
     ctx->have_scene = true;
@@ -479,9 +510,8 @@ int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width
         return fail(ctx, RT_ERR_NO_SCENE, "rt_set_scene has not been called");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     HitsArgs a;
-    a.conservative = (ctx->scene_tame && ctx->filter != kFilterExact) ? 1 : 0;
-    a.geom = a.conservative ? ctx->d_geom_filter : ctx->d_geom_exact;
-    a.r2 = ctx->d_r2;
+    a.geom = (ctx->scene_tame && ctx->filter != kFilterExact) ? ctx->d_geom_filter : nullptr;
+    a.exact = ctx->d_geom_exact;
     a.n = ctx->n_spheres; a.cam = *cam;
     a.width = width; a.height = height; a.hits = d_hits;
     RT_HIP(ctx, launch_primary_hits(a, (hipStream_t)stream));
@@ -537,9 +567,8 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out)
     hipError_t e = hipMemcpyAsync(d_rays, rays, in_bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         IntersectArgs a;
-        a.conservative = (ctx->scene_tame && ctx->filter != kFilterExact) ? 1 : 0;
-        a.geom = a.conservative ? ctx->d_geom_filter : ctx->d_geom_exact;
-        a.r2 = ctx->d_r2;
+        a.geom = (ctx->scene_tame && ctx->filter != kFilterExact) ? ctx->d_geom_filter : nullptr;
+        a.exact = ctx->d_geom_exact;
         a.spheres = ctx->d_spheres; a.n = ctx->n_spheres;
         a.rays = d_rays; a.n_rays = n; a.out = d_out;
         e = launch_intersect(a, ctx->stream);
@@ -563,15 +592,13 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
     case RT_OPT_FILTER:
         if (value == 0) ctx->filter = kFilterExact;
         else if (value == 1) ctx->filter = kFilterConservative;
-#ifdef RT_DIAGNOSTIC_KERNELS
-        else if (value == 2) ctx->filter = kFilterNoResolve;
-#endif
-        else return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_FILTER takes 0 or 1");
+        else if (value == 2) ctx->filter = kFilterMatrix;
+        else return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_FILTER takes 0, 1 or 2");
         return RT_OK;
     case RT_OPT_TILE_SPHERES:
-        if (value < kBlock || value > 8192)
-            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_TILE_SPHERES takes 32..8192");
-        ctx->tile_cap_max = (uint32_t)(value / kBlock) * kBlock;
+        if (value < kPad || value > 4096)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_TILE_SPHERES takes 128..4096");
+        ctx->tile_cap_max = (uint32_t)(value / kPad) * kPad;
         return RT_OK;
     case RT_OPT_WORKGROUPS_PER_CU:
         if (value < 0 || value > 8)

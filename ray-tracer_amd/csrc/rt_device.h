@@ -25,17 +25,18 @@ struct Geom {
 
 // How the scan decides which spheres need the exact root evaluation.
 enum {
-    kFilterExact = 0,        // the reference's own discriminant, unfused
-    kFilterConservative = 1, // fused, widened test: superset of the exact candidates
-    kFilterNoResolve = 2     // timing diagnostic (wrong images): phase 1 only
+    kFilterExact = 0,        // the reference's own discriminant, unfused, on the vector ALU
+    kFilterConservative = 1, // fused, widened test on the vector ALU: superset of the exact candidates
+    kFilterMatrix = 2        // the widened test as two 4-term products on the FP32 matrix cores
 };
 
 struct TraceArgs {
-    const Geom *geom;          // n records for `filter`, padded with zeros to a multiple of kBlock
-    const float *r2;           // exact squared radii, same padding
+    const Geom *geom;          // phase-1 records for `filter`, padded to a multiple of 128
+    const Geom *exact;         // {centre, fl(r*r)}, same padding
     const rt_sphere *spheres;  // n records, the caller's list
     uint32_t n;
     int32_t filter;
+    float shift[3];            // origin of the matrix filter's coordinates
     uint32_t tile_cap;         // spheres per LDS tile, multiple of kBlock
     rt_camera cam;
     uint32_t width, height;
@@ -58,9 +59,8 @@ struct ResolveArgs {
 };
 
 struct HitsArgs {
-    const Geom *geom;
-    const float *r2;
-    int32_t conservative;
+    const Geom *geom;          // conservative filter records, or null for the exact scan
+    const Geom *exact;
     uint32_t n;
     rt_camera cam;
     uint32_t width, height;
@@ -68,9 +68,8 @@ struct HitsArgs {
 };
 
 struct IntersectArgs {
-    const Geom *geom;
-    const float *r2;
-    int32_t conservative;
+    const Geom *geom;          // conservative filter records, or null for the exact scan
+    const Geom *exact;
     const rt_sphere *spheres;
     uint32_t n;
     const float *rays;
@@ -86,6 +85,6 @@ hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream);
 hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream);
 hipError_t launch_intersect(const IntersectArgs &a, hipStream_t stream);
 // Resident workgroups per CU of the trace kernel at this LDS size.
-hipError_t trace_occupancy(size_t lds_bytes, int *workgroups_per_cu);
+hipError_t trace_occupancy(int filter, size_t lds_bytes, int *workgroups_per_cu);
 
 } // namespace rtamd

@@ -65,11 +65,12 @@ __device__ __forceinline__ float unit_float(uint32_t w)
     return r >= 1.0f ? 0.99999994f : r;
 }
 
-// RandomFloat(-1.0f, 1.0f), Source/main.cpp:94-97: evaluated in double, then narrowed.
+// RandomFloat(-1.0f, 1.0f), Source/main.cpp:94-97: -1 + 2*r evaluated in double, then
+// narrowed.  2*r - 1 is exact in double for every float r in [0,1), so the narrowing is
+// the only rounding -- which is exactly what one float fma computes.
 __device__ __forceinline__ float range_m1_p1(uint32_t w)
 {
-    const double r = (double)unit_float(w);
-    return (float)(-1.0 + 2.0 * r);
+    return __builtin_fmaf(2.0f, unit_float(w), -1.0f);
 }
 
 // ---------------------------------------------------------------------------
@@ -199,13 +200,13 @@ __device__ __forceinline__ float filter_sign(const RayState &r, const Geom &s)
     return __builtin_fmaf(d, d, -(r.a_filter * c));
 }
 
-// IntersectSceneSpheres over one LDS tile (Source/main.cpp:534-546).  `tile`
-// holds `count` spheres padded to a multiple of kBlock and `r2` their exact
-// squared radii; `base` is the list index of tile[0].  Phase 1 (uniform, branch
+// IntersectSceneSpheres over one LDS tile (Source/main.cpp:534-546), one lane
+// per ray.  `filt` and `exact` hold `count` spheres padded to a multiple of
+// kBlock; `base` is the list index of record 0.  Phase 1 (uniform, branch
 // free): 32 early-out decisions per mask word.  Phase 2 (divergent, rare):
 // candidates in list order with the reference's arithmetic.
 template <int FILTER>
-__device__ __forceinline__ void scan_tile(const Geom *__restrict__ tile, const float *__restrict__ r2,
+__device__ __forceinline__ void scan_tile(const Geom *__restrict__ filt, const Geom *__restrict__ exact,
                                           uint32_t count, uint32_t base, const RayState &r, float tmin,
                                           float &closest, int &best)
 {
@@ -215,9 +216,7 @@ __device__ __forceinline__ void scan_tile(const Geom *__restrict__ tile, const f
 #pragma unroll
             for (int j = 0; j < kBlock; ++j) {
                 float B;
-                Geom s = tile[b + j];
-                s.r2 = r2[b + j];
-                const float disc = discriminant(r, s, B);
+                const float disc = discriminant(r, exact[b + j], B);
                 // the reference takes the hit branch unless disc < 0 (so also for NaN)
                 mask = (mask << 1) | (disc < 0.0f ? 0u : 1u);
             }
@@ -225,22 +224,187 @@ __device__ __forceinline__ void scan_tile(const Geom *__restrict__ tile, const f
             uint32_t reject = 0u;
 #pragma unroll
             for (int j = 0; j < kBlock; ++j) // shift the sign bit in from the right
-                reject = __builtin_amdgcn_alignbit(reject, __float_as_uint(filter_sign(r, tile[b + j])), 31);
+                reject = __builtin_amdgcn_alignbit(reject, __float_as_uint(filter_sign(r, filt[b + j])), 31);
             mask = r.tame ? ~reject : 0xFFFFFFFFu;
         }
         if (b + kBlock > count) // padding records of the last block
             mask &= ~(0xFFFFFFFFu >> (count - b));
-        if (FILTER == kFilterNoResolve) { // timing diagnostic only: keeps phase 1 alive, skips phase 2
-            best ^= (int)mask;
-            continue;
-        }
         while (mask) {
             const int j = __clz((int)mask);
             mask &= ~(0x80000000u >> j);
-            Geom s = tile[b + j];
-            s.r2 = r2[b + j];
-            if (resolve_candidate(r, s, tmin, closest))
+            if (resolve_candidate(r, exact[b + j], tmin, closest))
                 best = (int)(base + b + j);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Matrix-core scan: phase 1 on the FP32 MFMA pipe
+// ---------------------------------------------------------------------------
+//
+// The conservative test is bilinear in (ray, sphere) once expanded about a
+// common origin T (the scene's median centre): with o = O - T, c = C - T,
+//     d  = (o - c).D            = [c.x c.y c.z 1] . [-D.x -D.y -D.z  o.D]
+//     e  = -A' (|o - c|^2 - r2w) + m A' (|o|^2 + |c|^2)
+//        = [c.x c.y c.z K] . [2A'o.x 2A'o.y 2A'o.z -A'] - A' |o|^2 (1 - m),
+//     K  = |c|^2 (1 - m) - r2w,   A' = A (1 - 2^-17),  r2w = r^2 (1 + 2^-16),  m = 2^-18,
+// and the sphere is a candidate unless s = d^2 + e < 0.  Both 4-term products
+// are exactly what v_mfma_f32_16x16x4_f32 computes (a k-ordered fmaf chain,
+// the ray constant entering as the C operand), for 16 spheres x 16 rays per
+// instruction, on a pipe that runs beside the vector ALU.  The VALU is left
+// with one fma and one alignbit per test.
+//
+// Error budget (u = 2^-24, L = |o| + |c|): the fused chains and the roundings of
+// o, c, K, 2A'o and the constant perturb d^2 + e by at most
+// u A (16.7 L^2 + 2.1 L^2 + 16.3 (|o|^2+|c|^2) + 6.1 r2w) <= 53.8 u A' (|o|^2+|c|^2) + 6.2 u A r2w,
+// the reference accepts only if d*^2 - A (q* - r^2) >= -u A (16.7 q* + 2.1 r^2)
+// (its own roundings, see filter_sign), and the widening adds
+// 128 u A q* + 128 u A r^2 + 64 u A' (|o|^2 + |c|^2): every bracket stays
+// positive, so a sphere the reference accepts is never rejected.  Preconditions:
+// magnitudes below 2^28 after the shift, A and r^2 at least 2^-40; other rays
+// are scanned by the exact in-order loop instead, other scenes never use this
+// kernel.  Padding records are (0, 0, 0, K = 1e30): always rejected.
+//
+// Candidates of one ray come back spread over four lanes (the MFMA's row
+// groups); one ds_bpermute round per 128 spheres brings them to the ray's own
+// lane.  They are then resolved in whatever order the words hold them; the
+// reference's in-order rule (accept root <= closest) equals "smallest root,
+// then largest index", which is what resolve_unordered applies.
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kGroup = 128; // spheres per candidate word set (8 MFMA row tiles)
+
+struct MatrixOperands {
+    float b1[4], b2[4]; // per 16-ray column tile t: this lane's B elements of the two products
+    f32x4 c2[4];        // and the second product's C operand (the ray constant in all four rows)
+};
+
+// Effective root of RaySphereIntersectionTest (Source/main.cpp:490-499) for a
+// ray without NaNs: the near root if it is >= tmin, else the far root.
+__device__ __forceinline__ void resolve_unordered(const RayState &r, const Geom &s, int idx, float tmin,
+                                                  float &closest, int &best)
+{
+    float B;
+    const float disc = discriminant(r, s, B);
+    if (disc < 0.0f)
+        return;
+    const float sq = sqrtf(disc);
+    float root = (-B - sq) / r.two_a;
+    if (root < tmin)
+        root = (-B + sq) / r.two_a;
+    if (root >= tmin && (root < closest || (root == closest && idx > best))) {
+        closest = root;
+        best = idx;
+    }
+}
+
+// Publishes every lane's ray in matrix-operand form through the wave's LDS
+// staging area (9 x 64 floats) and reads back this lane's B/C elements.
+__device__ __forceinline__ void matrix_operands(const RayState &r, bool use, float tx, float ty, float tz,
+                                                float *stage, int lane, MatrixOperands &m)
+{
+    float v[9];
+    if (use) {
+        const float ox = r.ox - tx, oy = r.oy - ty, oz = r.oz - tz;
+        const float od = __builtin_fmaf(oz, r.dz, __builtin_fmaf(oy, r.dy, ox * r.dx));
+        const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+        const float ap = r.a_filter;       // A (1 - 2^-17)
+        const float ap2 = ap + ap;
+        v[0] = -r.dx; v[1] = -r.dy; v[2] = -r.dz; v[3] = od;
+        v[4] = ap2 * ox; v[5] = ap2 * oy; v[6] = ap2 * oz; v[7] = -ap;
+        v[8] = -(ap * oo) * (1.0f - 0x1p-18f);
+    } else { // idle or untame ray: d = 0, e = -1: every sphere rejected
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            v[q] = 0.0f;
+        v[8] = -1.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+        stage[q * 64 + lane] = v[q];
+    __builtin_amdgcn_wave_barrier();
+    const int c = lane & 15, k = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        m.b1[t] = stage[k * 64 + 16 * t + c];
+        m.b2[t] = stage[(4 + k) * 64 + 16 * t + c];
+        const float cc = stage[8 * 64 + 16 * t + c];
+        m.c2[t] = f32x4{ cc, cc, cc, cc };
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Whole-wave scan of one LDS tile.  `filt` holds {c.x, c.y, c.z, K} records and
+// `exact` the reference's {C, r*r}, both padded to a multiple of kGroup.  Must
+// be called by all 64 lanes; `mine` says whether this lane's own ray takes part.
+__device__ __forceinline__ void scan_tile_matrix(const float *__restrict__ filt,
+                                                 const Geom *__restrict__ exact, uint32_t count_padded,
+                                                 uint32_t base, const MatrixOperands &m, const RayState &r,
+                                                 bool mine, int lane, float tmin, float &closest, int &best)
+{
+    const int c = lane & 15, k = lane >> 4;
+    const f32x4 zero = { 0.0f, 0.0f, 0.0f, 0.0f };
+    for (uint32_t g0 = 0; g0 < count_padded; g0 += kGroup) {
+        uint32_t reject[4] = { 0u, 0u, 0u, 0u };
+        // Software pipeline, one stage deep: the two MFMAs of step i are issued, then the
+        // four fma + alignbit pairs of step i-1 run on results that are already complete, so
+        // the vector ALU never waits for the matrix pipe (they share the FP32 lanes: issue
+        // slots, not latency, are what is scarce).  A[i = c][k] of the next row tile is
+        // fetched one tile ahead (the last prefetch reads the array behind the tile; unused).
+        float a_next = filt[(g0 + c) * 4 + k];
+        f32x4 d_prev = zero, e_prev = zero;
+#pragma unroll 1
+        for (int st = 0; st < kGroup / 16; ++st) {
+            const float a2 = a_next;
+            a_next = filt[(g0 + 16 * (st + 1) + c) * 4 + k];
+            const float a1 = (k == 3) ? 1.0f : a2;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, m.b1[t], zero, 0, 0, 0);
+                const f32x4 e = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, m.b2[t], m.c2[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // the previous step's results: column tile t - 1 of this row tile, or column
+                // tile 3 of the previous row tile; row 4k + q, column c
+                const int tp = (t + 3) & 3;
+                if (t > 0 || st > 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        reject[tp] = __builtin_amdgcn_alignbit(
+                            reject[tp], __float_as_uint(__builtin_fmaf(d_prev[q], d_prev[q], e_prev[q])), 31);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                d_prev = d;
+                e_prev = e;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) // drain: column tile 3 of the last row tile
+            reject[3] = __builtin_amdgcn_alignbit(
+                reject[3], __float_as_uint(__builtin_fmaf(d_prev[q], d_prev[q], e_prev[q])), 31);
+        // bit 31 - (4 st + q) of w[t]: sphere g0 + 16 st + 4k + q, ray 16 t + c
+        const uint32_t w[4] = { ~reject[0], ~reject[1], ~reject[2], ~reject[3] };
+        // bring the four row-group words of ray `lane` (column tile k, column c) to this lane
+        uint32_t own[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int tsel = (k - j) & 3; // the column tile whose owner asks this lane in round j
+            const uint32_t pub = tsel == 0 ? w[0] : tsel == 1 ? w[1] : tsel == 2 ? w[2] : w[3];
+            const int src = c + 16 * ((k + j) & 3);
+            own[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src * 4, (int)pub);
+        }
+        if (mine) {
+            // one divergent loop for the four words: a lane with candidates in several words
+            // does not make the wave pay one pass per word
+            uint32_t o0 = own[0], o1 = own[1], o2 = own[2], o3 = own[3];
+            while ((o0 | o1 | o2 | o3) != 0u) {
+                const int j = o0 ? 0 : o1 ? 1 : o2 ? 2 : 3;
+                const uint32_t word = o0 ? o0 : o1 ? o1 : o2 ? o2 : o3;
+                const int pos = __clz((int)word);
+                const uint32_t rest = word & ~(0x80000000u >> pos);
+                if (j == 0) o0 = rest; else if (j == 1) o1 = rest; else if (j == 2) o2 = rest; else o3 = rest;
+                const uint32_t i = g0 + 16u * (uint32_t)(pos >> 2) + 4u * (uint32_t)((k + j) & 3) + (uint32_t)(pos & 3);
+                resolve_unordered(r, exact[i], (int)(base + i), tmin, closest, best);
+            }
         }
     }
 }
@@ -279,22 +443,27 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Copies spheres [t0, t0+cnt) of the padded geometry list and of the exact
-// squared radii into the LDS tile.
-__device__ __forceinline__ void load_tile(Geom *tile, float *tile_r2, const Geom *__restrict__ geom,
-                                          const float *__restrict__ r2, uint32_t t0, uint32_t cnt_padded)
+// Copies records [t0, t0+cnt_padded) of the filter's and of the exact geometry
+// list into the LDS tile (`filt` may be null when phase 1 reads the exact list).
+__device__ __forceinline__ void load_tile(Geom *tile_f, Geom *tile_e, const Geom *__restrict__ filt,
+                                          const Geom *__restrict__ exact, uint32_t t0, uint32_t cnt_padded)
 {
-    const float4 *src = reinterpret_cast<const float4 *>(geom + t0);
-    float4 *dst = reinterpret_cast<float4 *>(tile);
-    for (uint32_t i = threadIdx.x; i < cnt_padded; i += blockDim.x) {
-        dst[i] = src[i];
-        tile_r2[i] = r2[t0 + i];
+    const float4 *src_e = reinterpret_cast<const float4 *>(exact + t0);
+    float4 *dst_e = reinterpret_cast<float4 *>(tile_e);
+    for (uint32_t i = threadIdx.x; i < cnt_padded; i += blockDim.x)
+        dst_e[i] = src_e[i];
+    if (filt) {
+        const float4 *src_f = reinterpret_cast<const float4 *>(filt + t0);
+        float4 *dst_f = reinterpret_cast<float4 *>(tile_f);
+        for (uint32_t i = threadIdx.x; i < cnt_padded; i += blockDim.x)
+            dst_f[i] = src_f[i];
     }
 }
 
-__device__ __forceinline__ uint32_t round_up_block(uint32_t n)
+// Tiles are padded to whole candidate groups (a multiple of kBlock as well).
+__device__ __forceinline__ uint32_t round_up_group(uint32_t n)
 {
-    return (n + (kBlock - 1)) & ~(uint32_t)(kBlock - 1);
+    return (n + (kGroup - 1)) & ~(uint32_t)(kGroup - 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -303,22 +472,24 @@ __device__ __forceinline__ uint32_t round_up_block(uint32_t n)
 // ---------------------------------------------------------------------------
 
 template <bool MULTI_TILE, int FILTER>
-__global__ void __launch_bounds__(kTraceThreads) trace_kernel(const TraceArgs a)
+__global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    Geom *tile = reinterpret_cast<Geom *>(smem);
-    float *tile_r2 = reinterpret_cast<float *>(smem + (size_t)a.tile_cap * sizeof(Geom));
-    uint32_t *stack = reinterpret_cast<uint32_t *>(tile_r2 + a.tile_cap);
+    Geom *tile_f = reinterpret_cast<Geom *>(smem);
+    Geom *tile_e = tile_f + a.tile_cap;
+    float *stage = reinterpret_cast<float *>(tile_e + a.tile_cap); // 4 waves x 9 x 64 floats
+    uint32_t *stack = reinterpret_cast<uint32_t *>(stage + 4 * 9 * 64);
     const int stack_levels = a.max_depth > 0 ? a.max_depth : 1;
     uint32_t *wave_flags = stack + (size_t)stack_levels * kTraceThreads;
+    const Geom *filt_src = FILTER == kFilterExact ? nullptr : a.geom;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const uint32_t n_pad = round_up_block(a.n);
+    const uint32_t n_pad = round_up_group(a.n);
 
     if (!MULTI_TILE) {
-        load_tile(tile, tile_r2, a.geom, a.r2, 0u, n_pad);
+        load_tile(tile_f, tile_e, filt_src, a.exact, 0u, n_pad);
         __syncthreads();
     }
 
@@ -402,17 +573,26 @@ __global__ void __launch_bounds__(kTraceThreads) trace_kernel(const TraceArgs a)
         // ---- IntersectSceneSpheres(ray, 0.001f, inf), Source/main.cpp:562
         float closest = INFINITY;
         int best = -1;
-        if (MULTI_TILE) {
-            for (uint32_t t0 = 0u; t0 < a.n; t0 += a.tile_cap) {
-                const uint32_t cnt = min(a.tile_cap, a.n - t0);
+        MatrixOperands mo;
+        const bool mine = active && ray.tame; // this lane's ray goes through the matrix filter
+        if (FILTER == kFilterMatrix && wave_active)
+            matrix_operands(ray, mine, a.shift[0], a.shift[1], a.shift[2], stage + wave * (9 * 64), lane, mo);
+        for (uint32_t t0 = 0u; t0 < (MULTI_TILE ? a.n : 1u); t0 += a.tile_cap) {
+            const uint32_t cnt = MULTI_TILE ? min(a.tile_cap, a.n - t0) : a.n;
+            if (MULTI_TILE) {
                 __syncthreads(); // everyone is done with the previous tile (and with wave_flags)
-                load_tile(tile, tile_r2, a.geom, a.r2, t0, round_up_block(cnt));
+                load_tile(tile_f, tile_e, filt_src, a.exact, t0, round_up_group(cnt));
                 __syncthreads();
-                if (active)
-                    scan_tile<FILTER>(tile, tile_r2, cnt, t0, ray, 0.001f, closest, best);
             }
-        } else if (active) {
-            scan_tile<FILTER>(tile, tile_r2, a.n, 0u, ray, 0.001f, closest, best);
+            if (FILTER == kFilterMatrix) {
+                if (wave_active)
+                    scan_tile_matrix(reinterpret_cast<const float *>(tile_f), tile_e, round_up_group(cnt), t0, mo,
+                                     ray, mine, lane, 0.001f, closest, best);
+                if (active && !ray.tame) // NaN, Inf, zero or huge rays: the reference's in-order loop
+                    scan_tile<kFilterExact>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best);
+            } else if (active) {
+                scan_tile<FILTER>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best);
+            }
         }
         if (wave_active)
             ++n_rounds;
@@ -433,18 +613,19 @@ __global__ void __launch_bounds__(kTraceThreads) trace_kernel(const TraceArgs a)
                     hit_frame(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius,
                               px, py, pz, nx, ny, nz);
                     float ndx, ndy, ndz;
+                    // both branches draw exactly one point, and nothing else draws in between
+                    // (:566, :584), so the divergent rejection loop runs once for all lanes
+                    point_in_unit_sphere(pixel, sample, call, a.key0, a.key1, rx, ry, rz);
                     if (material == RT_MAT_DIFFUSE) {
                         // S = Normal + GeneratePointInUnitSphere(), :566
-                        point_in_unit_sphere(pixel, sample, call, a.key0, a.key1, rx, ry, rz);
                         ndx = nx + rx; ndy = ny + ry; ndz = nz + rz;
                     } else {
                         // glm::reflect: I - N * dot(N, I) * 2, then += fuzz * point, :583-584
                         const float d = nx * ray.dx + ny * ray.dy + nz * ray.dz;
+                        const float fuzz = sp->fuzz;
                         ndx = ray.dx - (nx * d) * 2.0f;
                         ndy = ray.dy - (ny * d) * 2.0f;
                         ndz = ray.dz - (nz * d) * 2.0f;
-                        point_in_unit_sphere(pixel, sample, call, a.key0, a.key1, rx, ry, rz);
-                        const float fuzz = sp->fuzz;
                         ndx = ndx + (fuzz * rx); ndy = ndy + (fuzz * ry); ndz = ndz + (fuzz * rz);
                     }
                     stack[level * kTraceThreads + tid] = (uint32_t)best;
@@ -513,8 +694,8 @@ __global__ void __launch_bounds__(256) resolve_kernel(const ResolveArgs a)
 __global__ void __launch_bounds__(256) primary_hits_kernel(const HitsArgs a, uint32_t tile_cap)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    Geom *tile = reinterpret_cast<Geom *>(smem);
-    float *tile_r2 = reinterpret_cast<float *>(smem + (size_t)tile_cap * sizeof(Geom));
+    Geom *tile_f = reinterpret_cast<Geom *>(smem);
+    Geom *tile_e = tile_f + tile_cap;
 
     // 64x4 pixel footprint per workgroup
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
@@ -530,13 +711,13 @@ __global__ void __launch_bounds__(256) primary_hits_kernel(const HitsArgs a, uin
     for (uint32_t t0 = 0u; t0 < a.n; t0 += tile_cap) {
         const uint32_t cnt = min(tile_cap, a.n - t0);
         __syncthreads();
-        load_tile(tile, tile_r2, a.geom, a.r2, t0, round_up_block(cnt));
+        load_tile(tile_f, tile_e, a.geom, a.exact, t0, round_up_group(cnt));
         __syncthreads();
         if (inside) {
-            if (a.conservative)
-                scan_tile<kFilterConservative>(tile, tile_r2, cnt, t0, ray, 0.001f, closest, best);
+            if (a.geom)
+                scan_tile<kFilterConservative>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best);
             else
-                scan_tile<kFilterExact>(tile, tile_r2, cnt, t0, ray, 0.001f, closest, best);
+                scan_tile<kFilterExact>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best);
         }
     }
     if (inside)
@@ -547,8 +728,8 @@ __global__ void __launch_bounds__(256) primary_hits_kernel(const HitsArgs a, uin
 __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, uint32_t tile_cap)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    Geom *tile = reinterpret_cast<Geom *>(smem);
-    float *tile_r2 = reinterpret_cast<float *>(smem + (size_t)tile_cap * sizeof(Geom));
+    Geom *tile_f = reinterpret_cast<Geom *>(smem);
+    Geom *tile_e = tile_f + tile_cap;
 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool inside = i < a.n_rays;
@@ -564,13 +745,13 @@ __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, u
     for (uint32_t t0 = 0u; t0 < a.n; t0 += tile_cap) {
         const uint32_t cnt = min(tile_cap, a.n - t0);
         __syncthreads();
-        load_tile(tile, tile_r2, a.geom, a.r2, t0, round_up_block(cnt));
+        load_tile(tile_f, tile_e, a.geom, a.exact, t0, round_up_group(cnt));
         __syncthreads();
         if (inside) {
-            if (a.conservative)
-                scan_tile<kFilterConservative>(tile, tile_r2, cnt, t0, ray, 0.001f, closest, best);
+            if (a.geom)
+                scan_tile<kFilterConservative>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best);
             else
-                scan_tile<kFilterExact>(tile, tile_r2, cnt, t0, ray, 0.001f, closest, best);
+                scan_tile<kFilterExact>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best);
         }
     }
     if (!inside)
@@ -602,8 +783,8 @@ __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, u
 size_t trace_lds_bytes(uint32_t tile_cap, int32_t max_depth)
 {
     const size_t levels = max_depth > 0 ? (size_t)max_depth : 1u;
-    return (size_t)tile_cap * (sizeof(Geom) + sizeof(float)) + levels * kTraceThreads * sizeof(uint32_t) +
-           4u * sizeof(uint32_t);
+    return (size_t)tile_cap * 2u * sizeof(Geom) + 4u * 9u * 64u * sizeof(float) +
+           levels * kTraceThreads * sizeof(uint32_t) + 4u * sizeof(uint32_t);
 }
 
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream)
@@ -624,19 +805,23 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
         else
             hipLaunchKernelGGL((trace_kernel<false, kFilterConservative>), grid, block, lds, stream, a);
         break;
-#ifdef RT_DIAGNOSTIC_KERNELS
-    case kFilterNoResolve:
-        hipLaunchKernelGGL((trace_kernel<false, kFilterNoResolve>), grid, block, lds, stream, a);
+    case kFilterMatrix:
+        if (multi)
+            hipLaunchKernelGGL((trace_kernel<true, kFilterMatrix>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((trace_kernel<false, kFilterMatrix>), grid, block, lds, stream, a);
         break;
-#endif
     default:
         return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t trace_occupancy(size_t lds_bytes, int *workgroups_per_cu)
+hipError_t trace_occupancy(int filter, size_t lds_bytes, int *workgroups_per_cu)
 {
+    if (filter == kFilterMatrix)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            workgroups_per_cu, trace_kernel<false, kFilterMatrix>, kTraceThreads, lds_bytes);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(
         workgroups_per_cu, trace_kernel<false, kFilterConservative>, kTraceThreads, lds_bytes);
 }
@@ -653,8 +838,8 @@ hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream)
 static uint32_t scan_tile_cap(uint32_t n)
 {
     // spheres per LDS tile for the one-lane-per-ray kernels: up to 32 KiB
-    const uint32_t n_pad = (n + (kBlock - 1)) & ~(uint32_t)(kBlock - 1);
-    return n_pad < 2048u ? (n_pad ? n_pad : kBlock) : 2048u;
+    const uint32_t n_pad = (n + (kGroup - 1)) & ~(uint32_t)(kGroup - 1);
+    return n_pad < 2048u ? (n_pad ? n_pad : kGroup) : 2048u;
 }
 
 hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream)
@@ -663,7 +848,7 @@ hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream)
         return hipSuccess;
     const uint32_t cap = scan_tile_cap(a.n);
     dim3 grid((a.width + 63u) / 64u, (a.height + 3u) / 4u);
-    hipLaunchKernelGGL(primary_hits_kernel, grid, dim3(256), (size_t)cap * (sizeof(Geom) + sizeof(float)), stream,
+    hipLaunchKernelGGL(primary_hits_kernel, grid, dim3(256), (size_t)cap * 2u * sizeof(Geom), stream,
                        a, cap);
     return hipGetLastError();
 }
@@ -674,7 +859,7 @@ hipError_t launch_intersect(const IntersectArgs &a, hipStream_t stream)
         return hipSuccess;
     const uint32_t cap = scan_tile_cap(a.n);
     hipLaunchKernelGGL(intersect_kernel, dim3((a.n_rays + 255u) / 256u), dim3(256),
-                       (size_t)cap * (sizeof(Geom) + sizeof(float)), stream, a, cap);
+                       (size_t)cap * 2u * sizeof(Geom), stream, a, cap);
     return hipGetLastError();
 }
 

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "librt_mi355x.so")
+LIB_PATH = os.environ.get("RTAMD_LIBRARY", os.path.join(os.path.dirname(_HERE), "librt_mi355x.so"))
 
 SPHERE_DTYPE = np.dtype(
     [("center", "<f4", 3), ("color", "<f4", 3), ("radius", "<f4"), ("material", "<i4"), ("fuzz", "<f4")]
@@ -19,7 +19,7 @@ assert SPHERE_DTYPE.itemsize == 36
 
 MAT_GLASS, MAT_DIFFUSE, MAT_METAL, MAT_FUZZYMETAL = 0, 1, 2, 3
 OPT_FILTER, OPT_TILE_SPHERES, OPT_WORKGROUPS_PER_CU = 0, 1, 2
-FILTER_EXACT, FILTER_CONSERVATIVE = 0, 1
+FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX = 0, 1, 2
 
 # every symbol include/rt_mi355x.h declares
 EXPORTS = [

@@ -60,7 +60,7 @@ def test_primary_hits_random_spheres_matches_reference_map(ctx, filt):
     ctx.set_option(rtamd.OPT_FILTER, filt)
     ctx.set_scene(c3_scene())
     got = ctx.primary_hits(rtamd.make_camera(*C3_CAM), 1920, 1080)
-    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_CONSERVATIVE)
+    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_MATRIX)
     want = np.load(os.path.join(G, "c2_c3scene_hits.npz"))["hits"]
     assert np.array_equal(got, want)
 
@@ -147,11 +147,13 @@ def test_frame_bit_exact_against_oracle(ctx, scene, cam, W, H, spp, depth, seed)
     assert ctx.stats().rays == rays
 
 
-def test_multi_tile_sphere_list_bit_exact(ctx):
-    """Sphere list longer than one LDS tile: 3 tiles of 64 plus a ragged one."""
-    sc = scenes.random_spheres(230, grid_half=8, seed=3)
+@pytest.mark.parametrize("filt", [rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX])
+def test_multi_tile_sphere_list_bit_exact(ctx, filt):
+    """Sphere list longer than one LDS tile: two tiles of 128 plus a ragged one of 44."""
+    sc = scenes.random_spheres(300, grid_half=9, seed=3)
     cam = C3_CAM
-    ctx.set_option(rtamd.OPT_TILE_SPHERES, 64)
+    ctx.set_option(rtamd.OPT_TILE_SPHERES, 128)
+    ctx.set_option(rtamd.OPT_FILTER, filt)
     try:
         ctx.set_scene(sc)
         ctx.reset_stats()
@@ -159,20 +161,44 @@ def test_multi_tile_sphere_list_bit_exact(ctx):
         rays_gpu = ctx.stats().rays
         hits = ctx.primary_hits(rtamd.make_camera(*cam), 160, 90)
     finally:
-        ctx.set_option(rtamd.OPT_TILE_SPHERES, 2048)
+        ctx.set_option(rtamd.OPT_TILE_SPHERES, 1024)
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_MATRIX)
     want, _, rays = O.trace_tile(sc, O.camera(*cam), 64, 36, 3, 6, O.RNG_COUNTER, seed=4)
     assert np.array_equal(got, want) and rays_gpu == rays
     assert np.array_equal(hits, O.primary_hits(sc, O.camera(*cam), 160, 90))
 
 
-def test_exact_and_conservative_scans_agree(ctx):
+def test_all_three_scans_agree(ctx):
+    """Unfused reference discriminant, fused vector filter and matrix-core filter: identical frames."""
     ctx.set_scene(c3_scene())
     cam, p = rtamd.make_camera(*C3_CAM), rtamd.params(480, 270, 8, 8, seed=5)
-    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_EXACT)
-    a = ctx.render(cam, p)
-    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_CONSERVATIVE)
-    b = ctx.render(cam, p)
-    assert np.array_equal(a, b)
+    frames = []
+    for filt in (rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX):
+        ctx.set_option(rtamd.OPT_FILTER, filt)
+        frames.append(ctx.render(cam, p))
+    assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])
+
+
+def test_matrix_filter_far_from_origin_and_degenerate_paths(ctx):
+    """The matrix filter expands about the scene's median centre; a scene 5000 units away from the
+    origin, with a tiny and a huge sphere mixed in, must still match the oracle bit for bit."""
+    rs = np.random.RandomState(21)
+    n = 150
+    sc = np.zeros(n, dtype=rtamd.SPHERE_DTYPE)
+    sc["center"] = (rs.uniform(-6, 6, size=(n, 3)) + np.array([5000.0, -3000.0, 4000.0])).astype(np.float32)
+    sc["radius"] = rs.uniform(0.2, 1.0, size=n).astype(np.float32)
+    sc["radius"][5] = 1e-3
+    sc["radius"][6] = 40.0
+    sc["material"] = rs.randint(0, 4, size=n)
+    sc["color"] = np.where((sc["material"] == 1)[:, None], rs.uniform(0, 255, (n, 3)), rs.uniform(0, 1, (n, 3)))
+    sc["fuzz"] = rs.uniform(0, 1, size=n)
+    cam = ((5000.0, -3000.0, 4020.0), (5000.0, -3000.0, 4000.0), (0.0, 1.0, 0.0), 40.0)
+    ctx.set_scene(sc)
+    ctx.reset_stats()
+    got = ctx.render(rtamd.make_camera(*cam), rtamd.params(96, 54, 6, 8, seed=12))
+    want, _, rays = O.trace_tile(sc, O.camera(*cam), 96, 54, 6, 8, O.RNG_COUNTER, seed=12)
+    assert np.array_equal(got, want) and ctx.stats().rays == rays
+    assert (got != got[0, 0]).any()  # something was hit
 
 
 def test_sub_tile_leaves_rest_of_frame_untouched(ctx):

@@ -40,15 +40,16 @@ print("c3 96x54x4 equal:", (img == ref).all(), "mismatch px:", int((img != ref).
 p = rtamd.params(480, 270, 8, 8, seed=5)
 ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_EXACT); ctx.reset_stats(); a = ctx.render(ccam, p); ra = ctx.stats().rays
 ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_CONSERVATIVE); ctx.reset_stats(); b = ctx.render(ccam, p); rb = ctx.stats().rays
-print("filters agree:", (a == b).all(), ra, rb, flush=True)
+ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_MATRIX); ctx.reset_stats(); c = ctx.render(ccam, p); rc = ctx.stats().rays
+print("filters agree:", (a == b).all(), (a == c).all(), "mismatch px", int((a != c).any(axis=2).sum()), ra, rb, rc, flush=True)
 
 # timed C3 frame
 W, H, SPP, D = 1920, 1080, 64, 8
 p = rtamd.params(W, H, SPP, D, seed=1)
 d_rgb = torch.empty(W * H * 3, dtype=torch.uint8, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
-for it in range(6):
-    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_EXACT if it < 2 else rtamd.FILTER_CONSERVATIVE)
+for it in range(9):
+    ctx.set_option(rtamd.OPT_FILTER, it // 3)
     ctx.reset_stats()
     torch.cuda.synchronize()
     t0 = time.time()
