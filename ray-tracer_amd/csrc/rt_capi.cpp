@@ -132,6 +132,8 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
 {
     if (rg.w == 0 || rg.h == 0)
         return RT_OK;
+    if (p->max_depth <= 0) // GetRayColor(ray, 0) is RGB(0,0,0) (Source/main.cpp:555-558): nothing to add
+        return RT_OK;
 
     TraceArgs a;
     memset(&a, 0, sizeof a);

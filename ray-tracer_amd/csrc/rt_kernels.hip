@@ -481,6 +481,7 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
     uint32_t *stack = reinterpret_cast<uint32_t *>(stage + 4 * 9 * 64);
     const int stack_levels = a.max_depth > 0 ? a.max_depth : 1;
     uint32_t *wave_flags = stack + (size_t)stack_levels * kTraceThreads;
+    uint32_t *acc_base = wave_flags + 4; // 4 waves x 2 chunk slots x 64 pixels x 3 channels
     const Geom *filt_src = FILTER == kFilterExact ? nullptr : a.geom;
 
     const int tid = threadIdx.x;
@@ -493,15 +494,25 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
         __syncthreads();
     }
 
-    // wave-uniform queue state
+    // Per-wave colour sums of the (at most two) chunks the wave has paths in flight for.  A
+    // chunk's 64 pixels belong to this wave alone during the launch, so its sums are added
+    // to the frame once, with plain loads and stores, when its last path has terminated.
+    uint32_t *acc = acc_base + wave * (2 * 64 * 3);
+    for (int i = lane; i < 2 * 64 * 3; i += 64)
+        acc[i] = 0u;
+
+    // wave-uniform queue state; slot s is free while s_total[s] == 0
     uint32_t w_next = 0u, w_end = 0u;
-    int ch_x0 = 0, ch_y0 = 0, ch_tw = 1, ch_npx = 1;
+    int cur = 0;
+    uint32_t s_total0 = 0u, s_total1 = 0u, s_done0 = 0u, s_done1 = 0u;
+    int s_x0[2] = { 0, 0 }, s_y0[2] = { 0, 0 }, s_tw[2] = { 1, 1 }, s_npx[2] = { 1, 1 };
     bool queue_empty = (a.sample_count == 0u);
 
     // per-lane path state
     bool active = false;
     RayState ray = {};
     uint32_t pixel = 0u, sample = 0u, call = 0u;
+    uint32_t acc_at = 0u; // index of this path's pixel in acc: slot * 192 + pixel-in-chunk * 3
     int depth = 0, level = 0;
     uint32_t n_rays = 0u;
     uint32_t n_rounds = 0u; // wave-uniform: passes over the sphere list
@@ -511,6 +522,11 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
         unsigned long long need = __ballot(!active);
         while (need != 0ull && !queue_empty) {
             if (w_next >= w_end) {
+                // a new chunk needs a free accumulator slot; with both in use the idle lanes
+                // wait until one of the two chunks in flight has drained
+                const int fs = s_total0 == 0u ? 0 : (s_total1 == 0u ? 1 : -1);
+                if (fs < 0)
+                    break;
                 uint32_t c = 0u;
                 if (lane == 0)
                     c = atomicAdd(a.chunk_counter, 1u);
@@ -521,14 +537,15 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                 }
                 const uint32_t t = a.tile_first + c * a.tile_stride;
                 const uint32_t ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-                ch_x0 = a.x0 + (int)tx * kTileW;
-                ch_y0 = a.y0 + (int)ty * kTileH;
-                ch_tw = min(kTileW, a.x0 + a.w - ch_x0);
-                const int th = min(kTileH, a.y0 + a.h - ch_y0);
-                ch_npx = ch_tw * th;
+                const int x0 = a.x0 + (int)tx * kTileW, y0 = a.y0 + (int)ty * kTileH;
+                const int tw = min(kTileW, a.x0 + a.w - x0), th = min(kTileH, a.y0 + a.h - y0);
+                cur = fs;
+                s_x0[fs] = x0; s_y0[fs] = y0; s_tw[fs] = tw; s_npx[fs] = tw * th;
                 w_next = 0u;
-                w_end = (uint32_t)ch_npx * a.sample_count;
+                w_end = (uint32_t)(tw * th) * a.sample_count;
+                if (fs == 0) { s_total0 = w_end; s_done0 = 0u; } else { s_total1 = w_end; s_done1 = 0u; }
             }
+            const int ch_x0 = s_x0[cur], ch_y0 = s_y0[cur], ch_tw = s_tw[cur], ch_npx = s_npx[cur];
             const uint32_t avail = w_end - w_next;
             const uint32_t rank = lane_rank(need);
             const bool got = ((need >> lane) & 1ull) && rank < avail;
@@ -541,16 +558,15 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                 const int px = ch_x0 + lx, py = ch_y0 + ly;
                 pixel = (uint32_t)px + (uint32_t)py * a.width;
                 sample = a.sample_begin + s;
+                acc_at = (uint32_t)cur * 192u + p * 3u;
                 call = 0u;
-                if (a.max_depth > 0) { // GetRayColor(ray, 0) is black: nothing to add
-                    uint32_t w[4];
-                    philox4x32_10(pixel, sample, call++, a.key0, a.key1, w);
-                    camera_ray(a.cam, a.width, a.height, px, py, (double)unit_float(w[0]),
-                               (double)unit_float(w[1]), ray);
-                    depth = a.max_depth;
-                    level = 0;
-                    active = true;
-                }
+                uint32_t w[4];
+                philox4x32_10(pixel, sample, call++, a.key0, a.key1, w);
+                camera_ray(a.cam, a.width, a.height, px, py, (double)unit_float(w[0]),
+                           (double)unit_float(w[1]), ray);
+                depth = a.max_depth; // >= 1: the host does not launch for RAY_DEPTH <= 0
+                level = 0;
+                active = true;
             }
             const uint32_t want = (uint32_t)__popcll(need);
             w_next += want < avail ? want : avail;
@@ -598,9 +614,9 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
             ++n_rounds;
 
         // ---- GetRayColor's branches, Source/main.cpp:562-597
+        bool terminated = false;
         if (active) {
             ++n_rays;
-            bool terminated = false;
             int cr = 0, cg = 0, cb = 0;
             if (best < 0) {
                 sky(ray.dy, cr, cg, cb);
@@ -653,11 +669,36 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                     cg = to_byte(sp->color[1] * (float)cg);
                     cb = to_byte(sp->color[2] * (float)cb);
                 }
-                uint32_t *dst = a.sums + (size_t)pixel * 3u;
-                atomicAdd(dst + 0, (uint32_t)cr);
-                atomicAdd(dst + 1, (uint32_t)cg);
-                atomicAdd(dst + 2, (uint32_t)cb);
+                // FinalColor += ray_color, :633-635
+                atomicAdd(acc + acc_at + 0u, (uint32_t)cr);
+                atomicAdd(acc + acc_at + 1u, (uint32_t)cg);
+                atomicAdd(acc + acc_at + 2u, (uint32_t)cb);
                 active = false;
+            }
+        }
+
+        // ---- chunks whose last path has just terminated: add their sums to the frame
+        const unsigned long long term = __ballot(terminated);
+        if (term != 0ull) {
+            const unsigned long long term1 = __ballot(terminated && acc_at >= 192u);
+            s_done1 += (uint32_t)__popcll(term1);
+            s_done0 += (uint32_t)__popcll(term & ~term1);
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const uint32_t total = sl ? s_total1 : s_total0, done = sl ? s_done1 : s_done0;
+                if (total != 0u && done == total) {
+                    if (lane < s_npx[sl]) {
+                        const int ly = lane / s_tw[sl], lx = lane - ly * s_tw[sl];
+                        uint32_t *dst = a.sums + ((size_t)(s_x0[sl] + lx) + (size_t)(s_y0[sl] + ly) * a.width) * 3u;
+                        uint32_t *src = acc + sl * 192 + lane * 3;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            dst[ch] += src[ch];
+                            src[ch] = 0u;
+                        }
+                    }
+                    if (sl) s_total1 = 0u; else s_total0 = 0u;
+                }
             }
         }
     }
@@ -784,7 +825,8 @@ size_t trace_lds_bytes(uint32_t tile_cap, int32_t max_depth)
 {
     const size_t levels = max_depth > 0 ? (size_t)max_depth : 1u;
     return (size_t)tile_cap * 2u * sizeof(Geom) + 4u * 9u * 64u * sizeof(float) +
-           levels * kTraceThreads * sizeof(uint32_t) + 4u * sizeof(uint32_t);
+           levels * kTraceThreads * sizeof(uint32_t) + 4u * sizeof(uint32_t) +
+           4u * 2u * 64u * 3u * sizeof(uint32_t);
 }
 
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream)
