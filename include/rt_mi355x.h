@@ -159,13 +159,13 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out);
 
 typedef enum rt_option {
     /* How the sphere scan finds the spheres that need the reference's exact root
-     * evaluation: 2 (default) a conservatively widened discriminant test as two
-     * 4-term products on the FP32 matrix cores; 1 the same kind of test with fused
+     * evaluation: 2 a conservatively widened discriminant test as two 4-term
+     * products on the FP32 matrix cores; 1 the same kind of test with fused
      * multiply-adds on the vector ALU; 0 the reference's own unfused discriminant
-     * for every sphere.  All three give bit-identical results; 0 and 1 exist to
-     * prove it and as fallbacks. */
+     * for every sphere; -1 (default) automatic: 2, or 1 for scenes of fewer than 96
+     * spheres.  All give bit-identical results; forcing one exists to prove it. */
     RT_OPT_FILTER = 0,
-    RT_OPT_TILE_SPHERES = 1,      /* spheres per LDS tile, 128..4096 (default 1024) */
+    RT_OPT_TILE_SPHERES = 1,      /* spheres per LDS tile, 128..4096 (default 512) */
     RT_OPT_WORKGROUPS_PER_CU = 2  /* cap on resident workgroups per CU, 0 = occupancy limit */
 } rt_option;
 

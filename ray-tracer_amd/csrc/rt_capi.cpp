@@ -35,6 +35,7 @@ struct rt_context {
     bool have_scene = false;
     bool scene_tame = false;       // every sphere within the conservative filters' preconditions
     int filter = kFilterMatrix;
+    bool filter_forced = false;    // set by RT_OPT_FILTER: no automatic choice by scene size
 
     uint32_t *d_chunk_counter = nullptr;
     unsigned long long *d_rays = nullptr;
@@ -44,7 +45,7 @@ struct rt_context {
     uint8_t *d_rgb = nullptr;   // scratch for rt_render
     size_t rgb_bytes = 0;
 
-    uint32_t tile_cap_max = 1024; // spheres per LDS tile (2 x 16 B each: 32 KiB)
+    uint32_t tile_cap_max = 512;  // spheres per LDS tile (2 x 16 B each: 16 KiB; 4 workgroups per CU)
     int wg_per_cu_override = 0;
 
     double last_kernel_ms = 0.0, last_wall_ms = 0.0;
@@ -138,6 +139,9 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     TraceArgs a;
     memset(&a, 0, sizeof a);
     a.filter = ctx->scene_tame ? ctx->filter : (int)kFilterExact;
+    // the matrix scan works on groups of 128 spheres; a handful of spheres is cheaper on the vector ALU
+    if (a.filter == kFilterMatrix && !ctx->filter_forced && ctx->n_spheres < 96u)
+        a.filter = kFilterConservative;
     a.geom = a.filter == kFilterMatrix ? ctx->d_geom_matrix : ctx->d_geom_filter;
     a.exact = ctx->d_geom_exact;
     memcpy(a.shift, ctx->shift, sizeof a.shift);
@@ -595,7 +599,9 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
         if (value == 0) ctx->filter = kFilterExact;
         else if (value == 1) ctx->filter = kFilterConservative;
         else if (value == 2) ctx->filter = kFilterMatrix;
-        else return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_FILTER takes 0, 1 or 2");
+        else if (value == -1) { ctx->filter = kFilterMatrix; ctx->filter_forced = false; return RT_OK; }
+        else return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_FILTER takes -1, 0, 1 or 2");
+        ctx->filter_forced = true;
         return RT_OK;
     case RT_OPT_TILE_SPHERES:
         if (value < kPad || value > 4096)

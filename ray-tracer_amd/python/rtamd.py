@@ -19,7 +19,7 @@ assert SPHERE_DTYPE.itemsize == 36
 
 MAT_GLASS, MAT_DIFFUSE, MAT_METAL, MAT_FUZZYMETAL = 0, 1, 2, 3
 OPT_FILTER, OPT_TILE_SPHERES, OPT_WORKGROUPS_PER_CU = 0, 1, 2
-FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX = 0, 1, 2
+FILTER_AUTO, FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX = -1, 0, 1, 2
 
 # every symbol include/rt_mi355x.h declares
 EXPORTS = [

@@ -60,7 +60,7 @@ def test_primary_hits_random_spheres_matches_reference_map(ctx, filt):
     ctx.set_option(rtamd.OPT_FILTER, filt)
     ctx.set_scene(c3_scene())
     got = ctx.primary_hits(rtamd.make_camera(*C3_CAM), 1920, 1080)
-    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_MATRIX)
+    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
     want = np.load(os.path.join(G, "c2_c3scene_hits.npz"))["hits"]
     assert np.array_equal(got, want)
 
@@ -161,8 +161,8 @@ def test_multi_tile_sphere_list_bit_exact(ctx, filt):
         rays_gpu = ctx.stats().rays
         hits = ctx.primary_hits(rtamd.make_camera(*cam), 160, 90)
     finally:
-        ctx.set_option(rtamd.OPT_TILE_SPHERES, 1024)
-        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_MATRIX)
+        ctx.set_option(rtamd.OPT_TILE_SPHERES, 512)
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
     want, _, rays = O.trace_tile(sc, O.camera(*cam), 64, 36, 3, 6, O.RNG_COUNTER, seed=4)
     assert np.array_equal(got, want) and rays_gpu == rays
     assert np.array_equal(hits, O.primary_hits(sc, O.camera(*cam), 160, 90))
@@ -176,7 +176,21 @@ def test_all_three_scans_agree(ctx):
     for filt in (rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX):
         ctx.set_option(rtamd.OPT_FILTER, filt)
         frames.append(ctx.render(cam, p))
+    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
     assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])
+
+
+def test_matrix_filter_on_a_four_sphere_scene(ctx):
+    """Forced matrix scan on the reference's own scene: 4 spheres padded to one group of 128."""
+    sc = rtamd.default_scene()
+    ctx.set_scene(sc)
+    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_MATRIX)
+    try:
+        got = ctx.render(rtamd.default_camera(), rtamd.params(128, 72, 8, 10, seed=7))
+    finally:
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
+    want, _, _ = O.trace_tile(sc, O.default_camera(), 128, 72, 8, 10, O.RNG_COUNTER, seed=7)
+    assert np.array_equal(got, want)
 
 
 def test_matrix_filter_far_from_origin_and_degenerate_paths(ctx):
