@@ -34,6 +34,14 @@ import rtamd
 import scenes
 
 W, H, SPP, DEPTH, N_SPHERES = 1920, 1080, 64, 8, 500
+
+# Other BASELINE.json configurations, selectable with --workload (the default and the headline
+# number is "c3"): name -> (width, height, frame spp or None for 64 per GPU, spheres, grid, partition)
+WORKLOADS = {
+    "c3": (1920, 1080, None, 500, 11, "samples"),   # configs[2]; weak scaling: 64 spp per GPU
+    "c4": (3840, 2160, 1024, 500, 11, "samples"),   # configs[3]: 1024 spp split over the GPUs
+    "c5": (1920, 1080, 256, 10000, 50, "tiles"),    # configs[4]: 10k spheres, tile-partitioned
+}
 FLOP_PER_TEST = 25.0          # miss path of RaySphereIntersectionTest, Source/main.cpp:475-479
 PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32: 256 CU x 128 FMA lanes x 2 x 2.4 GHz
 
@@ -82,7 +90,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--partition", choices=["samples", "tiles"], default="samples")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--partition", choices=["samples", "tiles"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -98,11 +107,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    global W, H, N_SPHERES
+    W, H, frame_spp, N_SPHERES, grid, default_partition = WORKLOADS[args.workload]
+    if args.partition is None:
+        args.partition = default_partition
     ctx = rtamd.Context(local_rank)
-    scene = scenes.random_spheres(N_SPHERES)
+    scene = scenes.random_spheres(N_SPHERES, grid_half=grid)
     ctx.set_scene(scene)
     cam = rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA)
-    total_spp = SPP * world
+    total_spp = SPP * world if frame_spp is None else frame_spp
     p = dist_render.rank_params(W, H, total_spp, DEPTH, 1, args.partition, rank, world)
     tracer = dist_render.DeviceTracer(ctx, cam)
 
@@ -181,13 +194,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if frame_spp is None else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "random-spheres scene, 500 spheres, 1920x1080, 64 spp per GPU, max depth 8 (BASELINE configs[2])",
-                "spheres": N_SPHERES, "width": W, "height": H, "spp_per_gpu": SPP, "frame_spp": total_spp,
+                "workload": {"c3": "random-spheres scene, 500 spheres, 1920x1080, 64 spp per GPU, max depth 8 (BASELINE configs[2])",
+                             "c4": "random-spheres scene, 500 spheres, 3840x2160, 1024 spp per frame, max depth 8 (BASELINE configs[3])",
+                             "c5": "random-spheres scene, 10000 spheres, 1920x1080, 256 spp per frame, max depth 8 (BASELINE configs[4])"}[args.workload],
+                "spheres": N_SPHERES, "width": W, "height": H, "frame_spp": total_spp,
                 "max_depth": DEPTH, "partition": args.partition,
                 "collective": "reduce(sum,int32,%d) to rank 0" % (W * H * 3) if world > 1 else "none",
             },
@@ -198,10 +213,10 @@ def main():
             "roofline": {
                 "bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                "flop_per_unit": "25 flop per ray-sphere test x 500 spheres per ray",
+                "flop_per_unit": "25 flop per ray-sphere test x %d spheres per ray" % N_SPHERES,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             line["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(line), flush=True)
 

@@ -1,7 +1,8 @@
-"""Timing breakdown of the trace kernel with the diagnostic library (phase 2 skipped = all rays miss)."""
-import os, sys, time
+"""Times the bench frame with the shipped library and with a diagnostic build (tools/librt_diag.so)."""
+import os, sys, time, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["RTAMD_LIBRARY"] = os.path.join(ROOT, "tools", "librt_diag.so")
+if len(sys.argv) > 1:
+    os.environ["RTAMD_LIBRARY"] = os.path.join(ROOT, "tools", sys.argv[1])
 sys.path.insert(0, os.path.join(ROOT, "ray-tracer_amd", "python"))
 import torch, rtamd, scenes
 ctx = rtamd.Context(0)
@@ -10,11 +11,11 @@ cam = rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA)
 W, H = 1920, 1080
 d = torch.zeros(W * H * 3, dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
-for filt, depth, name in ((1, 8, "full"), (2, 8, "phase-1 only (all miss)"), (1, 1, "full, depth 1"), (2, 1, "phase-1 only, depth 1")):
-    ctx._check(ctx._L.rt_set_option(ctx._h, 0, filt))
+for depth in (8, 1):
     p = rtamd.params(W, H, 64, depth, seed=1)
-    for it in range(3):
+    best = 1e9
+    for it in range(4):
         ctx.reset_stats(); torch.cuda.synchronize(); t0 = time.time()
-        ctx.accumulate_device(cam, p, d.data_ptr(), stream=s); torch.cuda.synchronize(); dt = time.time() - t0
+        ctx.accumulate_device(cam, p, d.data_ptr(), stream=s); torch.cuda.synchronize(); best = min(best, time.time() - t0)
     st = ctx.stats()
-    print(f"{name:28s} {dt*1e3:7.2f} ms  rays {st.rays:>10d}  ns/wave-pass {dt*1e9/st.wave_passes*1024:8.1f} (per SIMD)  util {st.rays/64/st.wave_passes:.3f}")
+    print(f"{os.environ.get('RTAMD_LIBRARY','shipped'):40s} depth {depth}: {best*1e3:7.2f} ms  rays {st.rays}  ps/ray {best*1e12/st.rays:6.1f}")
