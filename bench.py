@@ -43,7 +43,7 @@ WORKLOADS = {
     "c5": (1920, 1080, 256, 10000, 50, "tiles"),    # configs[4]: 10k spheres, tile-partitioned
 }
 FLOP_PER_TEST = 25.0          # miss path of RaySphereIntersectionTest, Source/main.cpp:475-479
-PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32: 256 CU x 128 FMA lanes x 2 x 2.4 GHz
+PEAK_FP32_TFLOPS = 157.3      # MI355X FP32, matrix (v_mfma_f32_*_f32) = vector: 256 CU x 128 FMA lanes x 2 x 2.4 GHz
 
 
 def cpu_baseline(scene):
@@ -186,7 +186,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "Mrays/s (incl. bounces) at 1080p 64spp",
+            "metric": "Mrays/s (incl. bounces) at 1080p 64spp" if args.workload == "c3" else "Mrays/s (incl. bounces)",
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -211,7 +211,8 @@ def main():
             "kernel_ms": kernel_ms,
             "kernel_ms_max_over_ranks": kernel_ms_max,
             "roofline": {
-                "bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "bound": "mfma", "pipe": "FP32 matrix/vector ALU (one shared pipe on gfx950)",
+                "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                 "flop_per_unit": "25 flop per ray-sphere test x %d spheres per ray" % N_SPHERES,
             },
