@@ -111,8 +111,8 @@ struct RayState {
 
 // Magnitude limits under which the conservative filter's arithmetic can neither
 // overflow nor lose its margin to underflow (see filter_sign).
-constexpr float kTameMax = 0x1p29f;  // |coordinate|, |direction component|
-constexpr float kTameMinA = 0x1p-60f; // dot(D,D)
+constexpr float kTameMax = 0x1p28f;   // |coordinate|, |direction component|
+constexpr float kTameMinA = 0x1p-40f; // dot(D,D)
 
 __device__ __forceinline__ void ray_prepare(RayState &r)
 {
@@ -191,8 +191,8 @@ __device__ __forceinline__ bool resolve_candidate(const RayState &r, const Geom 
 // so whenever the reference accepts, s >= u A (105 q* + 57 r^2) > 0: no false
 // reject.  False accepts (relative width 1e-5) only cost one exact evaluation.
 // Preconditions, checked per ray (RayState::tame) and per scene (host side):
-// every magnitude below 2^29 (no overflow: all intermediates stay under 2^127)
-// and A, r^2 >= 2^-60 (the margin exceeds any underflow loss by > 10^20).
+// every magnitude below 2^28 (no overflow: all intermediates stay under 2^127)
+// and A, r^2 >= 2^-40 (the margin exceeds any underflow loss by > 10^10).
 // Rays or scenes outside them take every sphere as a candidate.
 __device__ __forceinline__ float filter_sign(const RayState &r, const Geom &s)
 {

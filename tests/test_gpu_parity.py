@@ -307,6 +307,35 @@ def test_error_paths(ctx):
     fresh.close()
 
 
+@pytest.mark.parametrize("scale,offset", [(1e-3, 0.0), (1.0, 0.0), (37.0, 1e4), (1e3, -3e5), (1e5, 2e7)])
+def test_all_scans_agree_across_scene_scales(ctx, scale, offset):
+    """The conservative filters' margins are relative: shrink, blow up and move the scene; every scan
+    must keep giving the oracle's frame (far offsets make the float coordinates coarse, which is
+    exactly where a too-tight margin would drop a hit)."""
+    rs = np.random.RandomState(int(abs(offset)) % 1000 + 3)
+    n = 200
+    sc = np.zeros(n, dtype=rtamd.SPHERE_DTYPE)
+    sc["center"] = (rs.uniform(-8, 8, size=(n, 3)) * scale + offset).astype(np.float32)
+    sc["radius"] = (rs.uniform(0.3, 1.2, size=n) * scale).astype(np.float32)
+    sc["material"] = rs.randint(1, 3, size=n)
+    sc["color"] = np.where((sc["material"] == 1)[:, None], rs.uniform(0, 255, (n, 3)), rs.uniform(0.3, 1, (n, 3)))
+    sc["fuzz"] = rs.uniform(0, 0.5, size=n)
+    eye = np.array([0.0, 2.0, 30.0]) * scale + offset
+    cam = (tuple(eye), (offset, offset, offset), (0.0, 1.0, 0.0), 35.0)
+    want, _, rays = O.trace_tile(sc, O.camera(*cam), 64, 36, 4, 6, O.RNG_COUNTER, seed=5)
+    ctx.set_scene(sc)
+    try:
+        for filt in (rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX):
+            ctx.set_option(rtamd.OPT_FILTER, filt)
+            ctx.reset_stats()
+            got = ctx.render(rtamd.make_camera(*cam), rtamd.params(64, 36, 4, 6, seed=5))
+            assert np.array_equal(got, want), filt
+            assert ctx.stats().rays == rays
+    finally:
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
+    assert rays > 64 * 36 * 4  # some rays bounced: spheres were hit
+
+
 # ---------------------------------------------------------------- statistical parity with the reference
 
 
