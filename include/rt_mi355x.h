@@ -79,7 +79,22 @@ typedef struct rt_params {
     uint32_t sample_count; /*   sample_begin + sample_count); 0 = all spp */
     uint32_t tile_first;   /* of the 8x8-pixel tiles of the region, numbered row */
     uint32_t tile_stride;  /*   by row, trace tiles first, first+stride, ...; 0 or 1 = all */
+    uint32_t flags;        /* RT_FLAG_* extensions; 0 = the reference's behaviour */
+    uint32_t reserved;     /* must be 0 */
 } rt_params;
+
+/* Opt-in extensions.  The reference implements neither: its Glass spheres are flat white
+ * (Source/main.cpp:594) and it writes sum / SPP without a transfer curve (:638-642).  With
+ * flags == 0 results are the reference's; with a flag set they are checked against the same
+ * extension in the CPU oracle only. */
+enum {
+    /* Material::Glass scatters as a dielectric of index 1.5: Schlick reflectance against one
+     * RandomFloat() draw, glm::reflect / glm::refract (glm/detail/func_geometric.inl:110-127)
+     * on the normalised direction, colour = Color * child colour like Metal. */
+    RT_FLAG_DIELECTRIC = 1u,
+    /* rt_resolve / rt_render apply gamma 2: byte = trunc(sqrt((sum / spp) / 255) * 255). */
+    RT_FLAG_GAMMA2 = 2u
+};
 
 typedef struct rt_stats {
     uint64_t rays;            /* IntersectSceneSpheres calls (Source/main.cpp:562) since the last reset */
@@ -124,7 +139,17 @@ int rt_camera_init(const float lookfrom[3], const float lookat[3], const float u
 int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
               int ystart, int xsize, int ysize, uint8_t *rgb);
 
-/* Same, output left in device memory (`d_rgb`: full frame, width*height*3). */
+/* The reference shows the frame while it fills in (DoRenderLoop uploads g_PixelData every 15th
+ * display frame, Source/main.cpp:302-305).  This variant traces `samples_per_pass` samples at a
+ * time; after each pass the tile in `rgb` holds the average of the samples so far and `progress`
+ * (may be NULL) is called; a non-zero return stops the render (RT_OK, partial average kept).
+ * After the last pass `rgb` equals rt_render's output. */
+typedef int (*rt_progress_fn)(void *user, uint32_t samples_done, uint32_t samples_total);
+int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
+                          int ystart, int xsize, int ysize, uint8_t *rgb, uint32_t samples_per_pass,
+                          rt_progress_fn progress, void *user);
+
+/* Same as rt_render, output left in device memory (`d_rgb`: full frame, width*height*3). */
 int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
                      int ystart, int xsize, int ysize, uint8_t *d_rgb, void *stream);
 
@@ -137,9 +162,9 @@ int rt_accumulate_device(rt_context *ctx, const rt_camera *cam, const rt_params 
                          void *stream);
 
 /* FinalColor / SPP, ToRGB, PutPixel (Source/main.cpp:638-642) over the tile:
- * d_rgb = clamp(d_sums / spp_div, 0, 255). */
+ * d_rgb = clamp(d_sums / spp_div, 0, 255); `flags` may carry RT_FLAG_GAMMA2. */
 int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, uint32_t height,
-                      uint32_t spp_div, int xstart, int ystart, int xsize, int ysize,
+                      uint32_t spp_div, uint32_t flags, int xstart, int ystart, int xsize, int ysize,
                       uint8_t *d_rgb, void *stream);
 
 /* Deterministic primary-ray map: for every pixel, the index of the sphere that

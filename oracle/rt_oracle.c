@@ -106,6 +106,7 @@ typedef struct {
     orc_mt *mt;
     uint32_t key[2];
     uint32_t pixel, sample, call;
+    uint32_t flags; /* ORC_FLAG_*: extensions the reference does not have */
 } rng_t;
 
 /*
@@ -236,6 +237,7 @@ typedef struct {
     float point[3];
     float normal[3];
     float t;
+    int inside; /* normal was flipped: the ray travels inside the sphere (:510-514) */
 } hit_t;
 
 /* RaySphereIntersectionTest, Source/main.cpp:469-518. */
@@ -265,10 +267,12 @@ static int sphere_test(const orc_sphere *s, const float O[3], const float D[3], 
         rec->point[i] = O[i] + (D[i] * root);
     for (int i = 0; i < 3; i++)
         rec->normal[i] = (rec->point[i] - s->center[i]) / s->radius;
+    rec->inside = 0;
     if (dot3(D, rec->normal) > 0.0f) {
         rec->normal[0] = -rec->normal[0];
         rec->normal[1] = -rec->normal[1];
         rec->normal[2] = -rec->normal[2];
+        rec->inside = 1;
     }
     return 1;
 }
@@ -383,6 +387,43 @@ static void ray_color(const orc_sphere *spheres, uint32_t n, const float O[3], c
             out[i] = orc_to_byte(s->color[i] * (float)c[i]);
         return;
     }
+    if (s->material == ORC_MAT_GLASS && (rng->flags & ORC_FLAG_DIELECTRIC)) {
+        /* EXTENSION (not in the reference, whose Glass is flat white, :594): a dielectric of
+         * index 1.5 in the style of the book the reference follows.  One RandomFloat() draw
+         * decides between reflection and refraction; glm::reflect / glm::refract
+         * (func_geometric.inl:110-127) act on the normalised direction; every float operation
+         * is written out so that the GPU kernel can repeat it bit for bit. */
+        float inv = 1.0f / sqrtf(dot3(D, D));
+        float U[3] = { D[0] * inv, D[1] * inv, D[2] * inv };
+        float ratio = rec.inside ? 1.5f : (1.0f / 1.5f);
+        float nu = dot3(rec.normal, U); /* dot(N, I) <= 0: N opposes the ray */
+        float cos_theta = -nu;
+        if (cos_theta > 1.0f) cos_theta = 1.0f;
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        float r0 = (1.0f - ratio) / (1.0f + ratio);
+        r0 = r0 * r0;
+        float m = 1.0f - cos_theta;
+        float m5 = ((m * m) * (m * m)) * m;
+        float reflectance = r0 + (1.0f - r0) * m5;
+        uint32_t w[1];
+        rng_words(rng, 1, w);
+        float R[3];
+        if (ratio * sin_theta > 1.0f || reflectance > orc_u32_to_unit_float(w[0])) {
+            for (int i = 0; i < 3; i++)
+                R[i] = U[i] - (rec.normal[i] * nu) * 2.0f;
+        } else {
+            float k = 1.0f - (ratio * ratio) * (1.0f - nu * nu);
+            float f = ratio * nu + sqrtf(k);
+            float keep = k >= 0.0f ? 1.0f : 0.0f;
+            for (int i = 0; i < 3; i++)
+                R[i] = (ratio * U[i] - f * rec.normal[i]) * keep;
+        }
+        uint8_t c[3];
+        ray_color(spheres, n, rec.point, R, depth - 1, rng, rays, c);
+        for (int i = 0; i < 3; i++)
+            out[i] = orc_to_byte(s->color[i] * (float)c[i]);
+        return;
+    }
     out[0] = out[1] = out[2] = 255; /* :594 */
 }
 
@@ -408,6 +449,7 @@ void orc_sample_color(const orc_sphere *spheres, uint32_t n, const orc_camera *c
 {
     uint64_t local = 0;
     rng_t rng;
+    rng.flags = 0;
     rng.mode = ORC_RNG_COUNTER;
     rng.mt = NULL;
     rng.key[0] = (uint32_t)seed;
@@ -419,15 +461,33 @@ void orc_sample_color(const orc_sphere *spheres, uint32_t n, const orc_camera *c
     if (rays) *rays += local;
 }
 
-/* TraceThreadFunction, Source/main.cpp:613-645. */
 void orc_trace_tile(const orc_sphere *spheres, uint32_t n, const orc_camera *cam,
                     uint32_t width, uint32_t height, uint32_t s0, uint32_t s1, uint32_t spp_div,
                     int32_t max_depth, int rng_mode, uint64_t seed, orc_mt *mt, int xstart,
                     int ystart, int xsize, int ysize, uint8_t *rgb, uint32_t *sums,
                     uint64_t *rays)
 {
+    orc_trace_tile_ext(spheres, n, cam, width, height, s0, s1, spp_div, max_depth, rng_mode, seed, mt,
+                       xstart, ystart, xsize, ysize, 0u, rgb, sums, rays);
+}
+
+/* EXTENSION: gamma 2 on the averaged byte (the reference writes sum / SPP as is, :638-642). */
+uint8_t orc_gamma2(int32_t v)
+{
+    int32_t c = clampi(v, 0, 255);
+    return (uint8_t)clampi(float_to_int_x86(sqrtf((float)c / 255.0f) * 255.0f), 0, 255);
+}
+
+/* TraceThreadFunction, Source/main.cpp:613-645, plus the ORC_FLAG_* extensions. */
+void orc_trace_tile_ext(const orc_sphere *spheres, uint32_t n, const orc_camera *cam,
+                        uint32_t width, uint32_t height, uint32_t s0, uint32_t s1, uint32_t spp_div,
+                        int32_t max_depth, int rng_mode, uint64_t seed, orc_mt *mt, int xstart,
+                        int ystart, int xsize, int ysize, uint32_t flags, uint8_t *rgb, uint32_t *sums,
+                        uint64_t *rays)
+{
     uint64_t local = 0;
     rng_t rng;
+    rng.flags = flags;
     rng.mode = rng_mode;
     rng.mt = mt;
     rng.key[0] = (uint32_t)seed;
@@ -454,8 +514,10 @@ void orc_trace_tile(const orc_sphere *spheres, uint32_t n, const orc_camera *cam
                 sums[loc + 2] = (uint32_t)fin[2];
             }
             if (rgb) {
-                for (int c = 0; c < 3; c++)
-                    rgb[loc + c] = (uint8_t)clampi(fin[c] / (int32_t)spp_div, 0, 255);
+                for (int c = 0; c < 3; c++) {
+                    int32_t q = fin[c] / (int32_t)spp_div;
+                    rgb[loc + c] = (flags & ORC_FLAG_GAMMA2) ? orc_gamma2(q) : (uint8_t)clampi(q, 0, 255);
+                }
             }
         }
     }

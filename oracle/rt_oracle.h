@@ -101,6 +101,16 @@ void orc_trace_tile(const orc_sphere *spheres, uint32_t n, const orc_camera *cam
                     int ystart, int xsize, int ysize, uint8_t *rgb, uint32_t *sums,
                     uint64_t *rays);
 
+/* Extensions the reference does not have (default off everywhere): a real dielectric for
+ * Material::Glass, and gamma 2 on output.  Parity for them is CPU oracle <-> GPU only. */
+enum { ORC_FLAG_DIELECTRIC = 1u, ORC_FLAG_GAMMA2 = 2u };
+void orc_trace_tile_ext(const orc_sphere *spheres, uint32_t n, const orc_camera *cam,
+                        uint32_t width, uint32_t height, uint32_t s0, uint32_t s1, uint32_t spp_div,
+                        int32_t max_depth, int rng_mode, uint64_t seed, orc_mt *mt, int xstart,
+                        int ystart, int xsize, int ysize, uint32_t flags, uint8_t *rgb, uint32_t *sums,
+                        uint64_t *rays);
+uint8_t orc_gamma2(int32_t v);
+
 /* One sample's colour, Source/main.cpp:627-631; counter mode only. */
 void orc_sample_color(const orc_sphere *spheres, uint32_t n, const orc_camera *cam,
                       uint32_t width, uint32_t height, int32_t max_depth, uint64_t seed, int x,

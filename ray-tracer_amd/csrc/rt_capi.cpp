@@ -108,6 +108,8 @@ int check_params(rt_context *ctx, const rt_camera *cam, const rt_params *p)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "sample range exceeds spp");
     if (!p->sample_count && p->sample_begin != 0)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "sample_begin without sample_count");
+    if ((p->flags & ~(uint32_t)(RT_FLAG_DIELECTRIC | RT_FLAG_GAMMA2)) != 0u || p->reserved != 0u)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown flags");
     return RT_OK;
 }
 
@@ -153,6 +155,7 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     a.sample_begin = p->sample_begin;
     a.sample_count = p->sample_count ? p->sample_count : p->spp;
     a.max_depth = p->max_depth;
+    a.flags = p->flags;
     a.key0 = (uint32_t)p->seed;
     a.key1 = (uint32_t)(p->seed >> 32);
     a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
@@ -408,8 +411,8 @@ int rt_accumulate_device(rt_context *ctx, const rt_camera *cam, const rt_params 
 }
 
 int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, uint32_t height,
-                      uint32_t spp_div, int xstart, int ystart, int xsize, int ysize, uint8_t *d_rgb,
-                      void *stream)
+                      uint32_t spp_div, uint32_t flags, int xstart, int ystart, int xsize, int ysize,
+                      uint8_t *d_rgb, void *stream)
 {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
@@ -422,7 +425,7 @@ int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, u
     const Region rg = clip_region(p, xstart, ystart, xsize, ysize);
     ResolveArgs a;
     a.sums = d_sums; a.rgb = d_rgb;
-    a.width = width; a.height = height; a.spp_div = spp_div;
+    a.width = width; a.height = height; a.spp_div = spp_div; a.flags = flags;
     a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
     RT_HIP(ctx, launch_resolve(a, (hipStream_t)stream));
     return RT_OK;
@@ -453,7 +456,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *par
         return st;
     ResolveArgs a;
     a.sums = ctx->d_sums; a.rgb = d_rgb;
-    a.width = params->width; a.height = params->height; a.spp_div = params->spp;
+    a.width = params->width; a.height = params->height; a.spp_div = params->spp; a.flags = params->flags;
     a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
     RT_HIP(ctx, launch_resolve(a, s));
     return RT_OK;
@@ -503,6 +506,56 @@ int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, in
     (void)hipEventDestroy(e1);
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;
+}
+
+int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
+                          int ystart, int xsize, int ysize, uint8_t *rgb, uint32_t samples_per_pass,
+                          rt_progress_fn progress, void *user)
+{
+    int st = check_params(ctx, cam, params);
+    if (st != RT_OK)
+        return st;
+    if (!rgb || samples_per_pass == 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null rgb or zero samples_per_pass");
+    if (params->sample_count != 0 || params->sample_begin != 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "progressive render takes the whole sample range");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t frame_bytes = (size_t)params->width * params->height * 3u;
+    st = ensure(ctx, (void **)&ctx->d_rgb, &ctx->rgb_bytes, frame_bytes);
+    if (st == RT_OK)
+        st = ensure(ctx, (void **)&ctx->d_sums, &ctx->sums_bytes, frame_bytes * sizeof(uint32_t));
+    if (st != RT_OK)
+        return st;
+    const Region rg = clip_region(*params, xstart, ystart, xsize, ysize);
+    if (rg.w == 0 || rg.h == 0)
+        return RT_OK;
+    hipStream_t s = ctx->stream;
+    const size_t row_bytes = (size_t)params->width * 3u * sizeof(uint32_t);
+    RT_HIP(ctx, hipMemsetAsync((uint8_t *)ctx->d_sums + (size_t)rg.y0 * row_bytes, 0, (size_t)rg.h * row_bytes, s));
+    const size_t pitch = (size_t)params->width * 3u;
+    const size_t off = ((size_t)rg.x0 + (size_t)rg.y0 * params->width) * 3u;
+    for (uint32_t done = 0; done < params->spp;) {
+        rt_params pass = *params;
+        pass.sample_begin = done;
+        pass.sample_count = std::min(samples_per_pass, params->spp - done);
+        st = enqueue_accumulate(ctx, cam, &pass, rg, ctx->d_sums, s);
+        if (st != RT_OK)
+            return st;
+        done += pass.sample_count;
+        ResolveArgs a;
+        a.sums = ctx->d_sums; a.rgb = ctx->d_rgb;
+        a.width = params->width; a.height = params->height; a.spp_div = done; a.flags = params->flags;
+        a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
+        RT_HIP(ctx, launch_resolve(a, s));
+        RT_HIP(ctx, hipMemcpy2DAsync(rgb + off, pitch, ctx->d_rgb + off, pitch, (size_t)rg.w * 3u, (size_t)rg.h,
+                                     hipMemcpyDeviceToHost, s));
+        RT_HIP(ctx, hipStreamSynchronize(s));
+        if (progress && progress(user, done, params->spp) != 0)
+            break;
+    }
+    ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
 }
 
 int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width, uint32_t height,

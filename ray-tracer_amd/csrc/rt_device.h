@@ -42,6 +42,7 @@ struct TraceArgs {
     uint32_t width, height;
     uint32_t sample_begin, sample_count;
     int32_t max_depth;
+    uint32_t flags;            // RT_FLAG_*
     uint32_t key0, key1;
     int32_t x0, y0, w, h;      // traced region
     uint32_t tiles_x, tiles_y; // 8x8 tiles of the region
@@ -54,7 +55,7 @@ struct TraceArgs {
 struct ResolveArgs {
     const uint32_t *sums;
     uint8_t *rgb;
-    uint32_t width, height, spp_div;
+    uint32_t width, height, spp_div, flags;
     int32_t x0, y0, w, h;
 };
 

@@ -415,11 +415,12 @@ __device__ __forceinline__ void scan_tile_matrix(const float *__restrict__ filt,
 // Hit point and normal, Source/main.cpp:503-514.
 __device__ __forceinline__ void hit_frame(const RayState &r, float t, float cx, float cy, float cz,
                                           float radius, float &px, float &py, float &pz, float &nx,
-                                          float &ny, float &nz)
+                                          float &ny, float &nz, bool &inside)
 {
     px = r.ox + (r.dx * t); py = r.oy + (r.dy * t); pz = r.oz + (r.dz * t);
     nx = (px - cx) / radius; ny = (py - cy) / radius; nz = (pz - cz) / radius;
-    if ((r.dx * nx + r.dy * ny + r.dz * nz) > 0.0f) {
+    inside = (r.dx * nx + r.dy * ny + r.dz * nz) > 0.0f;
+    if (inside) {
         nx = -nx; ny = -ny; nz = -nz;
     }
 }
@@ -474,7 +475,7 @@ __device__ __forceinline__ uint32_t round_up_group(uint32_t n)
 // (Source/main.cpp:551-598, 613-645), iterative.
 // ---------------------------------------------------------------------------
 
-template <bool MULTI_TILE, int FILTER>
+template <bool MULTI_TILE, int FILTER, bool DIELECTRIC>
 __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -627,10 +628,56 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
             } else {
                 const rt_sphere *sp = a.spheres + best;
                 const int material = sp->material;
-                if (material == RT_MAT_DIFFUSE || material == RT_MAT_METAL) {
-                    float px, py, pz, nx, ny, nz, rx, ry, rz;
+                const bool dielectric = DIELECTRIC && material == RT_MAT_GLASS;
+                if (dielectric) {
+                    // EXTENSION (RT_FLAG_DIELECTRIC; the reference's Glass is flat white, :594):
+                    // index 1.5, Schlick reflectance against one RandomFloat() draw, glm::reflect /
+                    // glm::refract (func_geometric.inl:110-127) on the normalised direction.
+                    float px, py, pz, nx, ny, nz;
+                    bool inside;
                     hit_frame(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius,
-                              px, py, pz, nx, ny, nz);
+                              px, py, pz, nx, ny, nz, inside);
+                    const float inv = 1.0f / sqrtf(ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz);
+                    const float ux = ray.dx * inv, uy = ray.dy * inv, uz = ray.dz * inv;
+                    const float ratio = inside ? 1.5f : (1.0f / 1.5f);
+                    const float nu = nx * ux + ny * uy + nz * uz;
+                    float cos_theta = -nu;
+                    if (cos_theta > 1.0f)
+                        cos_theta = 1.0f;
+                    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                    float r0 = (1.0f - ratio) / (1.0f + ratio);
+                    r0 = r0 * r0;
+                    const float m1 = 1.0f - cos_theta;
+                    const float m5 = ((m1 * m1) * (m1 * m1)) * m1;
+                    const float reflectance = r0 + (1.0f - r0) * m5;
+                    uint32_t w[4];
+                    philox4x32_10(pixel, sample, call++, a.key0, a.key1, w);
+                    float ndx, ndy, ndz;
+                    if (ratio * sin_theta > 1.0f || reflectance > unit_float(w[0])) {
+                        ndx = ux - (nx * nu) * 2.0f;
+                        ndy = uy - (ny * nu) * 2.0f;
+                        ndz = uz - (nz * nu) * 2.0f;
+                    } else {
+                        const float kk = 1.0f - (ratio * ratio) * (1.0f - nu * nu);
+                        const float f = ratio * nu + sqrtf(kk);
+                        const float keep = kk >= 0.0f ? 1.0f : 0.0f;
+                        ndx = (ratio * ux - f * nx) * keep;
+                        ndy = (ratio * uy - f * ny) * keep;
+                        ndz = (ratio * uz - f * nz) * keep;
+                    }
+                    stack[level * kTraceThreads + tid] = (uint32_t)best;
+                    ++level;
+                    --depth;
+                    ray.ox = px; ray.oy = py; ray.oz = pz;
+                    ray.dx = ndx; ray.dy = ndy; ray.dz = ndz;
+                    ray_prepare(ray);
+                    if (depth <= 0)
+                        terminated = true;
+                } else if (material == RT_MAT_DIFFUSE || material == RT_MAT_METAL) {
+                    float px, py, pz, nx, ny, nz, rx, ry, rz;
+                    bool inside;
+                    hit_frame(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius,
+                              px, py, pz, nx, ny, nz, inside);
                     float ndx, ndy, ndz;
                     // both branches draw exactly one point, and nothing else draws in between
                     // (:566, :584), so the divergent rejection loop runs once for all lanes
@@ -728,8 +775,11 @@ __global__ void __launch_bounds__(256) resolve_kernel(const ResolveArgs a)
     const size_t loc = ((size_t)(a.x0 + (int)lx) + (size_t)(a.y0 + (int)ly) * a.width) * 3u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const uint32_t q = a.sums[loc + c] / a.spp_div;
-        a.rgb[loc + c] = (uint8_t)(q > 255u ? 255u : q);
+        uint32_t q = a.sums[loc + c] / a.spp_div;
+        q = q > 255u ? 255u : q;
+        if (a.flags & RT_FLAG_GAMMA2) // EXTENSION: the reference writes the average as is
+            q = (uint32_t)to_byte(sqrtf((float)q / 255.0f) * 255.0f);
+        a.rgb[loc + c] = (uint8_t)q;
     }
 }
 
@@ -806,8 +856,9 @@ __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, u
     if (best >= 0) {
         const rt_sphere *sp = a.spheres + best;
         float px, py, pz, nx, ny, nz;
+        bool inside;
         hit_frame(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius, px, py, pz,
-                  nx, ny, nz);
+                  nx, ny, nz, inside);
         of[1] = closest;
         of[2] = px; of[3] = py; of[4] = pz;
         of[5] = nx; of[6] = ny; of[7] = nz;
@@ -837,28 +888,26 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
     const size_t lds = trace_lds_bytes(a.tile_cap, a.max_depth);
     const bool multi = a.n > a.tile_cap;
     const dim3 grid(n_workgroups), block(kTraceThreads);
+    const bool glass = (a.flags & RT_FLAG_DIELECTRIC) != 0u;
+#define RT_LAUNCH_TRACE(F)                                                                        \
+    do {                                                                                          \
+        if (multi && glass)                                                                       \
+            hipLaunchKernelGGL((trace_kernel<true, F, true>), grid, block, lds, stream, a);       \
+        else if (multi)                                                                           \
+            hipLaunchKernelGGL((trace_kernel<true, F, false>), grid, block, lds, stream, a);      \
+        else if (glass)                                                                           \
+            hipLaunchKernelGGL((trace_kernel<false, F, true>), grid, block, lds, stream, a);      \
+        else                                                                                      \
+            hipLaunchKernelGGL((trace_kernel<false, F, false>), grid, block, lds, stream, a);     \
+    } while (0)
     switch (a.filter) {
-    case kFilterExact:
-        if (multi)
-            hipLaunchKernelGGL((trace_kernel<true, kFilterExact>), grid, block, lds, stream, a);
-        else
-            hipLaunchKernelGGL((trace_kernel<false, kFilterExact>), grid, block, lds, stream, a);
-        break;
-    case kFilterConservative:
-        if (multi)
-            hipLaunchKernelGGL((trace_kernel<true, kFilterConservative>), grid, block, lds, stream, a);
-        else
-            hipLaunchKernelGGL((trace_kernel<false, kFilterConservative>), grid, block, lds, stream, a);
-        break;
-    case kFilterMatrix:
-        if (multi)
-            hipLaunchKernelGGL((trace_kernel<true, kFilterMatrix>), grid, block, lds, stream, a);
-        else
-            hipLaunchKernelGGL((trace_kernel<false, kFilterMatrix>), grid, block, lds, stream, a);
-        break;
+    case kFilterExact: RT_LAUNCH_TRACE(kFilterExact); break;
+    case kFilterConservative: RT_LAUNCH_TRACE(kFilterConservative); break;
+    case kFilterMatrix: RT_LAUNCH_TRACE(kFilterMatrix); break;
     default:
         return hipErrorInvalidValue;
     }
+#undef RT_LAUNCH_TRACE
     return hipGetLastError();
 }
 
@@ -866,9 +915,9 @@ hipError_t trace_occupancy(int filter, size_t lds_bytes, int *workgroups_per_cu)
 {
     if (filter == kFilterMatrix)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            workgroups_per_cu, trace_kernel<false, kFilterMatrix>, kTraceThreads, lds_bytes);
+            workgroups_per_cu, trace_kernel<false, kFilterMatrix, false>, kTraceThreads, lds_bytes);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        workgroups_per_cu, trace_kernel<false, kFilterConservative>, kTraceThreads, lds_bytes);
+        workgroups_per_cu, trace_kernel<false, kFilterConservative, false>, kTraceThreads, lds_bytes);
 }
 
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream)

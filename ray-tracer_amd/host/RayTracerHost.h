@@ -15,6 +15,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rt_mi355x.h"
@@ -101,6 +102,7 @@ struct RenderState {
     unsigned Width = 1024, Height = 576; // g_Width, g_Height
     int SPP = 100, RAY_DEPTH = 10;       // :610-611
     uint64_t Seed = 0;
+    uint32_t Flags = 0;                  // RT_FLAG_*: 0 = the reference's shading and output
     std::vector<Sphere> Spheres = {      // :520-526
         Sphere(vec3(-1.0f, 0.0f, -1.0f), vec3(0.8f, 0.6f, 0.2f), 0.5f, Material::Metal, 0.65f),
         Sphere(vec3(0.0f, 0.0f, -1.0f), vec3(255, 0, 0), 0.5f, Material::Diffuse),
@@ -146,8 +148,26 @@ public:
         rt_params p;
         std::memset(&p, 0, sizeof p);
         p.width = s.Width; p.height = s.Height; p.spp = (uint32_t)s.SPP; p.max_depth = s.RAY_DEPTH; p.seed = s.Seed;
+        p.flags = s.Flags;
         if (s.PixelData.size() != (size_t)s.Width * s.Height * 3) s.AllocatePixels();
         Check(rt_render(m_Ctx, &s.SceneCamera.Pod(), &p, xstart, ystart, xsize, ysize, s.PixelData.data()));
+    }
+
+    // TraceScene + DoRenderLoop's periodic upload (Source/main.cpp:295-321): PixelData holds the
+    // average of the samples so far after every pass; OnPass returning false stops the trace.
+    template <class F> void TraceSceneProgressive(RenderState &s, uint32_t SamplesPerPass, F &&OnPass)
+    {
+        Check(rt_set_scene(m_Ctx, reinterpret_cast<const rt_sphere *>(s.Spheres.data()), (uint32_t)s.Spheres.size()));
+        rt_params p;
+        std::memset(&p, 0, sizeof p);
+        p.width = s.Width; p.height = s.Height; p.spp = (uint32_t)s.SPP; p.max_depth = s.RAY_DEPTH; p.seed = s.Seed;
+        p.flags = s.Flags;
+        if (s.PixelData.size() != (size_t)s.Width * s.Height * 3) s.AllocatePixels();
+        auto thunk = [](void *user, uint32_t done, uint32_t total) -> int {
+            return (*static_cast<typename std::remove_reference<F>::type *>(user))(done, total) ? 0 : 1;
+        };
+        Check(rt_render_progressive(m_Ctx, &s.SceneCamera.Pod(), &p, 0, 0, (int)s.Width, (int)s.Height,
+                                    s.PixelData.data(), SamplesPerPass, thunk, &OnPass));
     }
 
     // TraceScene: the reference splits the frame into THREAD_SPAWN_COUNT column strips; one device

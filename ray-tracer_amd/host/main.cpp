@@ -4,7 +4,8 @@
 //
 //   rt_render_cli [--width W --height H --spp N --depth D --seed S]
 //                 [--scene spheres.bin] [--camera fx fy fz ax ay az ux uy uz fov]
-//                 [--out image.ppm]
+//                 [--out image.ppm] [--progressive SAMPLES_PER_PASS]
+//                 [--dielectric] [--gamma2]      (extensions, off by default)
 // Defaults are the reference's shipped constants: 1024x576, 100 spp, depth 10,
 // its four spheres and its camera.
 #include "RayTracerHost.h"
@@ -37,6 +38,7 @@ int main(int argc, char **argv)
 {
     RenderState state;
     std::string out = "render.ppm";
+    unsigned per_pass = 0;
     try {
         for (int i = 1; i < argc; ++i) {
             const std::string a = argv[i];
@@ -47,6 +49,9 @@ int main(int argc, char **argv)
             else if (a == "--depth") { need(1); state.RAY_DEPTH = std::atoi(argv[++i]); }
             else if (a == "--seed") { need(1); state.Seed = std::strtoull(argv[++i], nullptr, 0); }
             else if (a == "--out") { need(1); out = argv[++i]; }
+            else if (a == "--progressive") { need(1); per_pass = (unsigned)std::atoi(argv[++i]); }
+            else if (a == "--dielectric") state.Flags |= RT_FLAG_DIELECTRIC;
+            else if (a == "--gamma2") state.Flags |= RT_FLAG_GAMMA2;
             else if (a == "--scene") {
                 need(1);
                 std::ifstream f(argv[++i], std::ios::binary | std::ios::ate);
@@ -70,7 +75,16 @@ int main(int argc, char **argv)
         std::cout << std::endl << "Writing Pixel Data.." << std::endl; // Source/main.cpp:663-664
         std::cout << "Ray Tracing.." << std::endl;
         const auto t0 = std::chrono::steady_clock::now();
-        tracer.TraceScene(state);
+        if (per_pass > 0) {
+            // the reference re-uploads g_PixelData every 20 frames while tracing (:302-305);
+            // here each pass leaves a complete picture, written over the same file
+            tracer.TraceSceneProgressive(state, per_pass, [&](uint32_t done, uint32_t total) {
+                std::printf("  %u / %u samples\n", done, total);
+                return WritePPM(out, state);
+            });
+        } else {
+            tracer.TraceScene(state);
+        }
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const rt_stats st = tracer.Stats();
         std::printf("%ux%u, %d spp, depth %d, %zu spheres: %llu rays in %.3f s (%.1f Mrays/s, kernels %.3f ms)\n",

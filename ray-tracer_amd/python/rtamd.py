@@ -24,7 +24,7 @@ FILTER_AUTO, FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX = -1, 0, 1, 2
 # every symbol include/rt_mi355x.h declares
 EXPORTS = [
     "rt_abi_version", "rt_status_string", "rt_last_error", "rt_create", "rt_destroy", "rt_set_scene",
-    "rt_camera_init", "rt_render", "rt_render_device", "rt_accumulate_device", "rt_resolve_device",
+    "rt_camera_init", "rt_render", "rt_render_progressive", "rt_render_device", "rt_accumulate_device", "rt_resolve_device",
     "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_get_stats", "rt_reset_stats",
 ]
 
@@ -49,6 +49,8 @@ class Params(C.Structure):
         ("sample_count", C.c_uint32),
         ("tile_first", C.c_uint32),
         ("tile_stride", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -99,7 +101,8 @@ def load():
     L.rt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp]
     L.rt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, vp]
     L.rt_accumulate_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, vp]
-    L.rt_resolve_device.argtypes = [vp, vp, u32, u32, u32, i, i, i, i, vp, vp]
+    L.rt_render_progressive.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, u32, PROGRESS_FN, vp]
+    L.rt_resolve_device.argtypes = [vp, vp, u32, u32, u32, u32, i, i, i, i, vp, vp]
     L.rt_primary_hits.argtypes = [vp, C.POINTER(Camera), u32, u32, vp]
     L.rt_primary_hits_device.argtypes = [vp, C.POINTER(Camera), u32, u32, vp, vp]
     L.rt_intersect.argtypes = [vp, vp, u32, vp]
@@ -134,8 +137,13 @@ def default_scene():
     return s
 
 
-def params(width, height, spp, max_depth, seed=0, sample_begin=0, sample_count=0, tile_first=0, tile_stride=0):
-    return Params(width, height, spp, max_depth, seed, sample_begin, sample_count, tile_first, tile_stride)
+FLAG_DIELECTRIC, FLAG_GAMMA2 = 1, 2
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)
+
+
+def params(width, height, spp, max_depth, seed=0, sample_begin=0, sample_count=0, tile_first=0, tile_stride=0,
+           flags=0):
+    return Params(width, height, spp, max_depth, seed, sample_begin, sample_count, tile_first, tile_stride, flags, 0)
 
 
 class Context:
@@ -190,10 +198,21 @@ class Context:
             tile = (0, 0, p.width, p.height)
         self._check(self._L.rt_accumulate_device(self._h, C.byref(cam), C.byref(p), *tile, d_sums, stream))
 
-    def resolve_device(self, d_sums, width, height, spp_div, d_rgb, tile=None, stream=None):
+    def resolve_device(self, d_sums, width, height, spp_div, d_rgb, tile=None, stream=None, flags=0):
         if tile is None:
             tile = (0, 0, width, height)
-        self._check(self._L.rt_resolve_device(self._h, d_sums, width, height, spp_div, *tile, d_rgb, stream))
+        self._check(self._L.rt_resolve_device(self._h, d_sums, width, height, spp_div, flags, *tile, d_rgb, stream))
+
+    def render_progressive(self, cam, p, samples_per_pass, on_pass=None, tile=None, rgb=None, fill=255):
+        """on_pass(samples_done, samples_total, rgb) -> truthy to stop."""
+        if tile is None:
+            tile = (0, 0, p.width, p.height)
+        if rgb is None:
+            rgb = np.full((p.height, p.width, 3), fill, dtype=np.uint8)
+        cb = PROGRESS_FN(lambda user, done, total: 1 if (on_pass and on_pass(done, total, rgb)) else 0)
+        self._check(self._L.rt_render_progressive(self._h, C.byref(cam), C.byref(p), *tile, rgb.ctypes.data,
+                                                  samples_per_pass, cb, None))
+        return rgb
 
     def primary_hits(self, cam, width, height):
         out = np.empty((height, width), dtype=np.int32)

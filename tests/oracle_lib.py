@@ -67,6 +67,13 @@ def lib():
             C.c_uint32, C.c_int32, C.c_int, C.c_uint64, C.POINTER(MT), C.c_int, C.c_int, C.c_int, C.c_int,
             C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
         ]
+        L.orc_trace_tile_ext.argtypes = [
+            C.c_void_p, C.c_uint32, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+            C.c_uint32, C.c_int32, C.c_int, C.c_uint64, C.POINTER(MT), C.c_int, C.c_int, C.c_int, C.c_int,
+            C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
+        ]
+        L.orc_gamma2.argtypes = [C.c_int32]
+        L.orc_gamma2.restype = C.c_uint8
         L.orc_sample_color.argtypes = [
             C.c_void_p, C.c_uint32, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64,
             C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64),
@@ -118,8 +125,11 @@ def new_mt(seed=5489):
     return g
 
 
+FLAG_DIELECTRIC, FLAG_GAMMA2 = 1, 2
+
+
 def trace_tile(spheres, cam, width, height, spp, depth, rng_mode, seed=0, mt=None, tile=None,
-               s0=0, s1=None, rgb=None, want_sums=False, fill=255):
+               s0=0, s1=None, rgb=None, want_sums=False, fill=255, flags=0):
     """TraceThreadFunction on `tile` = (xstart, ystart, xsize, ysize); returns (rgb, sums, rays)."""
     spheres = np.ascontiguousarray(spheres)
     if tile is None:
@@ -132,9 +142,9 @@ def trace_tile(spheres, cam, width, height, spp, depth, rng_mode, seed=0, mt=Non
     rays = C.c_uint64(0)
     if rng_mode == RNG_MT19937 and mt is None:
         mt = new_mt()
-    lib().orc_trace_tile(
+    lib().orc_trace_tile_ext(
         spheres.ctypes.data, len(spheres), C.byref(cam), width, height, s0, s1, spp, depth, rng_mode, seed,
-        C.byref(mt) if mt is not None else None, tile[0], tile[1], tile[2], tile[3],
+        C.byref(mt) if mt is not None else None, tile[0], tile[1], tile[2], tile[3], flags,
         rgb.ctypes.data, sums.ctypes.data if sums is not None else None, C.byref(rays),
     )
     return rgb, sums, rays.value

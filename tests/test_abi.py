@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert rtamd.SPHERE_DTYPE.itemsize == 36  # class Sphere, Source/main.cpp:362-391
     assert C.sizeof(rtamd.Camera) == 48
-    assert C.sizeof(rtamd.Params) == 40
+    assert C.sizeof(rtamd.Params) == 48
     assert C.sizeof(rtamd.Stats) == 40
 
 
