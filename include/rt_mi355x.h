@@ -187,14 +187,25 @@ typedef enum rt_option {
      * evaluation: 2 a conservatively widened discriminant test as two 4-term
      * products on the FP32 matrix cores; 1 the same kind of test with fused
      * multiply-adds on the vector ALU; 0 the reference's own unfused discriminant
-     * for every sphere; -1 (default) automatic: 2, or 1 for scenes of fewer than 96
-     * spheres.  All give bit-identical results; forcing one exists to prove it. */
+     * for every sphere; 3 a per-ray walk of a bounding-box hierarchy built over the list
+     * (the reference has none: it tests every sphere, Source/main.cpp:534), whose boxes are
+     * padded so that no sphere the reference accepts is skipped; -1 (default) automatic:
+     * 3 from RT_OPT_BVH_MIN_SPHERES spheres up, else 2, or 1 below 96 spheres.  All give
+     * bit-identical results; forcing one exists to prove it. */
     RT_OPT_FILTER = 0,
     RT_OPT_TILE_SPHERES = 1,      /* spheres per LDS tile, 128..4096 (default 512) */
-    RT_OPT_WORKGROUPS_PER_CU = 2  /* cap on resident workgroups per CU, 0 = occupancy limit */
+    RT_OPT_WORKGROUPS_PER_CU = 2, /* cap on resident workgroups per CU, 0 = occupancy limit */
+    RT_OPT_BVH_LEAF_SPHERES = 3,  /* most spheres per leaf of the hierarchy, 1..15 (default 4) */
+    RT_OPT_BVH_MIN_SPHERES = 4    /* scene size from which the automatic choice is the hierarchy */
 } rt_option;
 
 int rt_set_option(rt_context *ctx, int option, int64_t value);
+
+/* Builds the hierarchy of RT_OPT_FILTER 3 for `spheres` on the host and checks its structure
+ * (every sphere in exactly one leaf or on the always-tested list, every box contains what is
+ * below it).  Needs no device.  info (may be NULL) = {nodes, levels, always-tested spheres,
+ * records}.  No counterpart in the reference. */
+int rt_accel_selfcheck(const rt_sphere *spheres, uint32_t n, int leaf_spheres, uint32_t info[4]);
 
 /* Counters ---------------------------------------------------------------- */
 

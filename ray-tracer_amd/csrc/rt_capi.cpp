@@ -4,6 +4,7 @@
 // head, the ray counter and the scratch frame buffers, validates arguments and
 // enqueues the kernels of rt_kernels.hip.  There is no CPU implementation of
 // the path behind this boundary: without a HIP device every call fails.
+#include "rt_bvh.h"
 #include "rt_device.h"
 
 #include <algorithm>
@@ -36,6 +37,17 @@ struct rt_context {
     bool scene_tame = false;       // every sphere within the conservative filters' preconditions
     int filter = kFilterMatrix;
     bool filter_forced = false;    // set by RT_OPT_FILTER: no automatic choice by scene size
+
+    // host copies kept for the hierarchy, which is built on first use
+    std::vector<rt_sphere> h_spheres;
+    std::vector<Geom> h_exact;
+    BvhHost bvh;                   // without the node / record arrays once they are on the device
+    bool bvh_ready = false;
+    int bvh_leaf_max = 4;
+    uint32_t bvh_auto_min = 1024;  // automatic choice: hierarchy from this many spheres up
+    float4 *d_bvh_nodes = nullptr;
+    Geom *d_bvh_geom = nullptr;
+    uint32_t *d_bvh_index = nullptr;
 
     uint32_t *d_chunk_counter = nullptr;
     unsigned long long *d_rays = nullptr;
@@ -129,6 +141,48 @@ int ensure(rt_context *ctx, void **ptr, size_t *have, size_t want)
     return RT_OK;
 }
 
+void drop_bvh(rt_context *ctx)
+{
+    if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);
+    if (ctx->d_bvh_geom) (void)hipFree(ctx->d_bvh_geom);
+    if (ctx->d_bvh_index) (void)hipFree(ctx->d_bvh_index);
+    ctx->d_bvh_nodes = nullptr;
+    ctx->d_bvh_geom = nullptr;
+    ctx->d_bvh_index = nullptr;
+    ctx->bvh = BvhHost();
+    ctx->bvh_ready = false;
+}
+
+// Builds the hierarchy over the current scene and copies it to the device (once per scene
+// and leaf size).
+int ensure_bvh(rt_context *ctx)
+{
+    if (ctx->bvh_ready)
+        return RT_OK;
+    drop_bvh(ctx);
+    BvhHost &b = ctx->bvh;
+    bvh_build(ctx->h_spheres.data(), ctx->h_exact.data(), ctx->n_spheres, ctx->bvh_leaf_max, b);
+    if (b.levels > 96u)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "hierarchy deeper than 96 levels");
+    const size_t nb = std::max<size_t>(b.nodes.size(), 1) * sizeof(BvhNode);
+    const size_t gb = std::max<size_t>(b.leaf_geom.size(), 1) * sizeof(Geom);
+    const size_t ib = std::max<size_t>(b.leaf_index.size(), 1) * sizeof(uint32_t);
+    if (hipMalloc((void **)&ctx->d_bvh_nodes, nb) != hipSuccess || hipMalloc((void **)&ctx->d_bvh_geom, gb) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_bvh_index, ib) != hipSuccess) {
+        drop_bvh(ctx);
+        return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for the hierarchy");
+    }
+    if (!b.nodes.empty())
+        RT_HIP(ctx, hipMemcpy(ctx->d_bvh_nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    if (!b.leaf_geom.empty()) {
+        RT_HIP(ctx, hipMemcpy(ctx->d_bvh_geom, b.leaf_geom.data(), b.leaf_geom.size() * sizeof(Geom), hipMemcpyHostToDevice));
+        RT_HIP(ctx, hipMemcpy(ctx->d_bvh_index, b.leaf_index.data(), b.leaf_index.size() * sizeof(uint32_t),
+                              hipMemcpyHostToDevice));
+    }
+    ctx->bvh_ready = true;
+    return RT_OK;
+}
+
 // Enqueues the sample loop for `region` into d_sums.
 int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p, const Region &rg,
                        uint32_t *d_sums, hipStream_t stream)
@@ -144,6 +198,24 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     // the matrix scan works on groups of 128 spheres; a handful of spheres is cheaper on the vector ALU
     if (a.filter == kFilterMatrix && !ctx->filter_forced && ctx->n_spheres < 96u)
         a.filter = kFilterConservative;
+    if (a.filter == kFilterMatrix && !ctx->filter_forced && ctx->n_spheres >= ctx->bvh_auto_min)
+        a.filter = kFilterBvh;
+    if (a.filter == kFilterBvh) {
+        const int st = ensure_bvh(ctx);
+        if (st != RT_OK)
+            return st;
+        const BvhHost &b = ctx->bvh;
+        a.bvh.nodes = ctx->d_bvh_nodes;
+        a.bvh.leaf_geom = ctx->d_bvh_geom;
+        a.bvh.leaf_index = ctx->d_bvh_index;
+        a.bvh.n_nodes = (uint32_t)b.nodes.size();
+        a.bvh.n_large = b.n_large;
+        a.bvh.levels = b.levels;
+        memcpy(a.bvh.center, b.center, sizeof a.bvh.center);
+        a.bvh.radius = b.radius;
+        a.bvh.rmin = b.rmin;
+        a.bvh.rmin2w = b.rmin2w;
+    }
     a.geom = a.filter == kFilterMatrix ? ctx->d_geom_matrix : ctx->d_geom_filter;
     a.exact = ctx->d_geom_exact;
     memcpy(a.shift, ctx->shift, sizeof a.shift);
@@ -178,8 +250,11 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     // LDS tile: the whole (padded) list when it fits, else tiles of tile_cap_max
     const uint32_t n_pad = (a.n + (kPad - 1)) & ~(uint32_t)(kPad - 1);
     a.tile_cap = n_pad <= ctx->tile_cap_max ? (n_pad ? n_pad : kPad) : ctx->tile_cap_max;
+    if (a.filter == kFilterBvh)
+        a.tile_cap = 0u; // the walk reads nodes and leaf records from memory
+    a.aux_bytes = trace_aux_bytes(a.filter, a.bvh.levels);
 
-    const size_t lds = trace_lds_bytes(a.tile_cap, a.max_depth);
+    const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth);
     if (lds > 160u * 1024u)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_depth too large for the LDS bounce stack");
     int per_cu = 0;
@@ -264,6 +339,7 @@ int rt_destroy(rt_context *ctx)
     if (ctx->d_geom_filter) (void)hipFree(ctx->d_geom_filter);
     if (ctx->d_geom_matrix) (void)hipFree(ctx->d_geom_matrix);
     if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
+    drop_bvh(ctx);
     if (ctx->d_chunk_counter) (void)hipFree(ctx->d_chunk_counter);
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
@@ -288,6 +364,7 @@ int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n)
     if (ctx->d_geom_matrix) { RT_HIP(ctx, hipFree(ctx->d_geom_matrix)); ctx->d_geom_matrix = nullptr; }
     if (ctx->d_spheres) { RT_HIP(ctx, hipFree(ctx->d_spheres)); ctx->d_spheres = nullptr; }
     ctx->have_scene = false;
+    drop_bvh(ctx);
 
     const uint32_t n_pad = (n + (kPad - 1)) & ~(uint32_t)(kPad - 1);
     const size_t cnt = n_pad ? n_pad : kPad;
@@ -349,6 +426,8 @@ int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n)
     if (n)
         RT_HIP(ctx, hipMemcpy(ctx->d_spheres, spheres, (size_t)n * sizeof(rt_sphere), hipMemcpyHostToDevice));
     memcpy(ctx->shift, shift, sizeof shift);
+    ctx->h_spheres.assign(spheres, spheres + n);
+    ctx->h_exact.assign(exact.begin(), exact.begin() + n);
     ctx->scene_tame = tame;
     ctx->n_spheres = n;
     ctx->have_scene = true;
@@ -652,8 +731,9 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
         if (value == 0) ctx->filter = kFilterExact;
         else if (value == 1) ctx->filter = kFilterConservative;
         else if (value == 2) ctx->filter = kFilterMatrix;
+        else if (value == 3) ctx->filter = kFilterBvh;
         else if (value == -1) { ctx->filter = kFilterMatrix; ctx->filter_forced = false; return RT_OK; }
-        else return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_FILTER takes -1, 0, 1 or 2");
+        else return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_FILTER takes -1, 0, 1, 2 or 3");
         ctx->filter_forced = true;
         return RT_OK;
     case RT_OPT_TILE_SPHERES:
@@ -666,9 +746,47 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_WORKGROUPS_PER_CU takes 0..8");
         ctx->wg_per_cu_override = (int)value;
         return RT_OK;
+    case RT_OPT_BVH_LEAF_SPHERES:
+        if (value < 1 || value > kBvhLeafMax)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_LEAF_SPHERES takes 1..15");
+        if (ctx->bvh_leaf_max != (int)value) {
+            RT_HIP(ctx, hipSetDevice(ctx->device));
+            RT_HIP(ctx, hipDeviceSynchronize());
+            drop_bvh(ctx);
+            ctx->bvh_leaf_max = (int)value;
+        }
+        return RT_OK;
+    case RT_OPT_BVH_MIN_SPHERES:
+        if (value < 1 || value > (1ll << 30))
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_MIN_SPHERES takes 1..2^30");
+        ctx->bvh_auto_min = (uint32_t)value;
+        return RT_OK;
     default:
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option");
     }
+}
+
+int rt_accel_selfcheck(const rt_sphere *spheres, uint32_t n, int leaf_spheres, uint32_t info[4])
+{
+    if ((n && !spheres) || leaf_spheres < 1 || leaf_spheres > kBvhLeafMax)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::vector<Geom> exact(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        volatile float rr = spheres[i].radius * spheres[i].radius;
+        exact[i].cx = spheres[i].center[0];
+        exact[i].cy = spheres[i].center[1];
+        exact[i].cz = spheres[i].center[2];
+        exact[i].r2 = rr;
+    }
+    BvhHost b;
+    bvh_build(spheres, exact.data(), n, leaf_spheres, b);
+    if (info) {
+        info[0] = (uint32_t)b.nodes.size();
+        info[1] = b.levels;
+        info[2] = b.n_large;
+        info[3] = (uint32_t)b.leaf_geom.size();
+    }
+    return bvh_validate(spheres, n, b).empty() ? RT_OK : RT_ERR_INVALID_ARGUMENT;
 }
 
 int rt_get_stats(rt_context *ctx, rt_stats *stats)

@@ -27,7 +27,19 @@ struct Geom {
 enum {
     kFilterExact = 0,        // the reference's own discriminant, unfused, on the vector ALU
     kFilterConservative = 1, // fused, widened test on the vector ALU: superset of the exact candidates
-    kFilterMatrix = 2        // the widened test as two 4-term products on the FP32 matrix cores
+    kFilterMatrix = 2,       // the widened test as two 4-term products on the FP32 matrix cores
+    kFilterBvh = 3           // per-ray walk of a box hierarchy; the spheres in the leaves reached are candidates
+};
+
+// Device view of the hierarchy (see rt_bvh.h for the encoding).
+struct BvhArgs {
+    const float4 *nodes;        // four float4 per node
+    const Geom *leaf_geom;      // n_large always-tested records, then the leaves' records
+    const uint32_t *leaf_index; // list index of each record
+    uint32_t n_nodes, n_large;
+    uint32_t levels;            // traversal stack entries per ray
+    float center[3];            // origin of the boxes' coordinates
+    float radius, rmin, rmin2w; // see BvhHost
 };
 
 struct TraceArgs {
@@ -37,7 +49,9 @@ struct TraceArgs {
     uint32_t n;
     int32_t filter;
     float shift[3];            // origin of the matrix filter's coordinates
-    uint32_t tile_cap;         // spheres per LDS tile, multiple of kBlock
+    uint32_t tile_cap;         // spheres per LDS tile, multiple of kBlock (0: no tiles)
+    uint32_t aux_bytes;        // LDS between the tiles and the bounce stack: operand staging or traversal stack
+    BvhArgs bvh;               // kFilterBvh only
     rt_camera cam;
     uint32_t width, height;
     uint32_t sample_begin, sample_count;
@@ -78,8 +92,10 @@ struct IntersectArgs {
     uint8_t *out; // 32 bytes per ray
 };
 
+// Bytes of LDS between the tiles and the bounce stack for `filter`.
+uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels);
 // Bytes of dynamic LDS the trace kernel needs.
-size_t trace_lds_bytes(uint32_t tile_cap, int32_t max_depth);
+size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth);
 
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream);
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream);

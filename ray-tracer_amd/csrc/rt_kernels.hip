@@ -412,6 +412,108 @@ __device__ __forceinline__ void scan_tile_matrix(const float *__restrict__ filt,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Hierarchy scan: a per-ray walk over boxes instead of a pass over the list
+// ---------------------------------------------------------------------------
+//
+// A conservative filter like the two above, with the ray deciding which part
+// of the list it looks at: spheres in leaves the walk does not reach are those
+// the reference cannot accept, the others go through resolve_unordered.
+//
+// Why skipping a box is safe.  Write oc for the reference's rounded O - C,
+// q = |oc|^2, and take its acceptance condition from filter_sign: the hit branch
+// is taken only if the line through C + oc along D passes within
+//     dist^2 <= r^2 + u (19.8 q + 5.2 r^2),                       u = 2^-24,
+// of the centre, and the root T it then accepts lies (with the roundings of
+// B, the square root and the division) at a point whose distance from C is below
+//     r_eff = sqrt(r^2 (1 + 64u) + 64u q).
+// So the segment [tmin, closest] of the line meets the ball of radius r_eff at the
+// accepted T, hence also every box that contains the sphere's box once it is
+// padded by r_eff - |r|, which is largest for the smallest radius in the tree:
+//     pad >= sqrt(rmin^2 (1 + 64u) + 64u qmax) - rmin,   qmax = (|O - center| + radius)^2 >= q.
+// The slab test runs in coordinates relative to the tree's centre; its own
+// roundings move a plane by less than 8u (|O - center| + radius) and scale a t by
+// less than 1 + 4u, which the extra 32u (|O - center| + radius) + 8u r_eff of padding,
+// the factor 1.001 on the whole and the 2^-20 relative slack on [tmin, closest]
+// cover.  A direction component too small to divide by is replaced by
+// 2^-50 of the largest one: over any distance inside the tree that moves the ray
+// by less than 2^-49 of the tree's size.  Only tame rays walk the tree.
+__device__ __forceinline__ void bvh_closest_hit(const BvhArgs &b, const RayState &r, uint32_t *stk, float tmin,
+                                                float &closest, int &best)
+{
+    for (uint32_t i = 0; i < b.n_large; ++i)
+        resolve_unordered(r, b.leaf_geom[i], (int)b.leaf_index[i], tmin, closest, best);
+    if (b.n_nodes == 0u)
+        return;
+
+    const float ox = r.ox - b.center[0], oy = r.oy - b.center[1], oz = r.oz - b.center[2];
+    const float reach = (sqrtf(__builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox))) + b.radius) * (1.0f + 0x1p-20f);
+    const float reff = sqrtf(__builtin_fmaf(reach * reach, 0x1p-18f, b.rmin2w));
+    const float pad = ((reff - b.rmin) + __builtin_fmaf(reach, 0x1p-19f, reff * 0x1p-21f)) * 1.001f;
+
+    const float dmax = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz));
+    const float dlim = dmax * 0x1p-50f;
+    const float ddx = fabsf(r.dx) < dlim ? copysignf(dlim, r.dx) : r.dx;
+    const float ddy = fabsf(r.dy) < dlim ? copysignf(dlim, r.dy) : r.dy;
+    const float ddz = fabsf(r.dz) < dlim ? copysignf(dlim, r.dz) : r.dz;
+    const float ix = __builtin_amdgcn_rcpf(ddx), iy = __builtin_amdgcn_rcpf(ddy), iz = __builtin_amdgcn_rcpf(ddz);
+    // t at plane p: (p - o) / d = fma(p, i, n); lower planes are moved by -pad, upper by +pad
+    const float nlx = -((ox + pad) * ix), nly = -((oy + pad) * iy), nlz = -((oz + pad) * iz);
+    const float nhx = -((ox - pad) * ix), nhy = -((oy - pad) * iy), nhz = -((oz - pad) * iz);
+    const float t_lo = tmin * (1.0f - 0x1p-20f);
+    float t_hi = closest * (1.0f + 0x1p-20f);
+
+    constexpr int kDone = INT_MIN;
+    int node = 0;
+    uint32_t sp = 0u;
+    for (;;) {
+        while (node >= 0) {
+            const float4 *np = b.nodes + (size_t)node * 4u;
+            const float4 l0 = np[0], h0 = np[1], l1 = np[2], h1 = np[3];
+            float a0, a1, n0, n1, f0, f1;
+            a0 = __builtin_fmaf(l0.x, ix, nlx); a1 = __builtin_fmaf(h0.x, ix, nhx);
+            n0 = fminf(a0, a1); f0 = fmaxf(a0, a1);
+            a0 = __builtin_fmaf(l0.y, iy, nly); a1 = __builtin_fmaf(h0.y, iy, nhy);
+            n0 = fmaxf(n0, fminf(a0, a1)); f0 = fminf(f0, fmaxf(a0, a1));
+            a0 = __builtin_fmaf(l0.z, iz, nlz); a1 = __builtin_fmaf(h0.z, iz, nhz);
+            n0 = fmaxf(fmaxf(n0, fminf(a0, a1)), t_lo); f0 = fminf(fminf(f0, fmaxf(a0, a1)), t_hi);
+            a0 = __builtin_fmaf(l1.x, ix, nlx); a1 = __builtin_fmaf(h1.x, ix, nhx);
+            n1 = fminf(a0, a1); f1 = fmaxf(a0, a1);
+            a0 = __builtin_fmaf(l1.y, iy, nly); a1 = __builtin_fmaf(h1.y, iy, nhy);
+            n1 = fmaxf(n1, fminf(a0, a1)); f1 = fminf(f1, fmaxf(a0, a1));
+            a0 = __builtin_fmaf(l1.z, iz, nlz); a1 = __builtin_fmaf(h1.z, iz, nhz);
+            n1 = fmaxf(fmaxf(n1, fminf(a0, a1)), t_lo); f1 = fminf(fminf(f1, fmaxf(a0, a1)), t_hi);
+            const bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+            const int c0 = __float_as_int(l0.w), c1 = __float_as_int(h0.w);
+            if (hit0 && hit1) {
+                const bool first0 = n0 <= n1;
+                stk[sp * kTraceThreads] = (uint32_t)(first0 ? c1 : c0);
+                ++sp;
+                node = first0 ? c0 : c1;
+            } else if (hit0) {
+                node = c0;
+            } else if (hit1) {
+                node = c1;
+            } else if (sp == 0u) {
+                node = kDone;
+            } else {
+                --sp;
+                node = (int)stk[sp * kTraceThreads];
+            }
+        }
+        if (node == kDone)
+            break;
+        const uint32_t code = (uint32_t)~node, first = code >> 4, count = code & 15u;
+        for (uint32_t i = first; i < first + count; ++i)
+            resolve_unordered(r, b.leaf_geom[i], (int)b.leaf_index[i], tmin, closest, best);
+        t_hi = closest * (1.0f + 0x1p-20f);
+        if (sp == 0u)
+            break;
+        --sp;
+        node = (int)stk[sp * kTraceThreads];
+    }
+}
+
 // Hit point and normal, Source/main.cpp:503-514.
 __device__ __forceinline__ void hit_frame(const RayState &r, float t, float cx, float cy, float cz,
                                           float radius, float &px, float &py, float &pz, float &nx,
@@ -481,8 +583,10 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
     extern __shared__ __align__(16) unsigned char smem[];
     Geom *tile_f = reinterpret_cast<Geom *>(smem);
     Geom *tile_e = tile_f + a.tile_cap;
-    float *stage = reinterpret_cast<float *>(tile_e + a.tile_cap); // 4 waves x 9 x 64 floats
-    uint32_t *stack = reinterpret_cast<uint32_t *>(stage + 4 * 9 * 64);
+    // matrix scan: 4 waves x 9 x 64 floats of operand staging; hierarchy scan: the walk's
+    // stack, levels x 256 node references
+    float *stage = reinterpret_cast<float *>(tile_e + a.tile_cap);
+    uint32_t *stack = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(stage) + a.aux_bytes);
     const int stack_levels = a.max_depth > 0 ? a.max_depth : 1;
     uint32_t *wave_flags = stack + (size_t)stack_levels * kTraceThreads;
     uint32_t *acc_base = wave_flags + 4; // 4 waves x 2 chunk slots x 64 pixels x 3 channels
@@ -493,7 +597,7 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
     const int wave = tid >> 6;
     const uint32_t n_pad = round_up_group(a.n);
 
-    if (!MULTI_TILE) {
+    if (!MULTI_TILE && FILTER != kFilterBvh) {
         load_tile(tile_f, tile_e, filt_src, a.exact, 0u, n_pad);
         __syncthreads();
     }
@@ -597,7 +701,15 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
         const bool mine = active && ray.tame; // this lane's ray goes through the matrix filter
         if (FILTER == kFilterMatrix && wave_active)
             matrix_operands(ray, mine, a.shift[0], a.shift[1], a.shift[2], stage + wave * (9 * 64), lane, mo);
-        for (uint32_t t0 = 0u; t0 < (MULTI_TILE ? a.n : 1u); t0 += a.tile_cap) {
+        if (FILTER == kFilterBvh) {
+            if (active) {
+                if (ray.tame)
+                    bvh_closest_hit(a.bvh, ray, reinterpret_cast<uint32_t *>(stage) + tid, 0.001f, closest, best);
+                else // the reference's in-order loop over the whole list, from memory
+                    scan_tile<kFilterExact>(a.exact, a.exact, a.n, 0u, ray, 0.001f, closest, best);
+            }
+        }
+        for (uint32_t t0 = 0u; FILTER != kFilterBvh && t0 < (MULTI_TILE ? a.n : 1u); t0 += a.tile_cap) {
             const uint32_t cnt = MULTI_TILE ? min(a.tile_cap, a.n - t0) : a.n;
             if (MULTI_TILE) {
                 __syncthreads(); // everyone is done with the previous tile (and with wave_flags)
@@ -875,18 +987,25 @@ __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, u
 // Launch wrappers
 // ---------------------------------------------------------------------------
 
-size_t trace_lds_bytes(uint32_t tile_cap, int32_t max_depth)
+uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels)
+{
+    if (filter == kFilterBvh)
+        return (bvh_levels ? bvh_levels : 1u) * kTraceThreads * (uint32_t)sizeof(uint32_t);
+    return 4u * 9u * 64u * (uint32_t)sizeof(float);
+}
+
+size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth)
 {
     const size_t levels = max_depth > 0 ? (size_t)max_depth : 1u;
-    return (size_t)tile_cap * 2u * sizeof(Geom) + 4u * 9u * 64u * sizeof(float) +
+    return (size_t)tile_cap * 2u * sizeof(Geom) + aux_bytes +
            levels * kTraceThreads * sizeof(uint32_t) + 4u * sizeof(uint32_t) +
            4u * 2u * 64u * 3u * sizeof(uint32_t);
 }
 
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream)
 {
-    const size_t lds = trace_lds_bytes(a.tile_cap, a.max_depth);
-    const bool multi = a.n > a.tile_cap;
+    const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth);
+    const bool multi = a.filter != kFilterBvh && a.n > a.tile_cap;
     const dim3 grid(n_workgroups), block(kTraceThreads);
     const bool glass = (a.flags & RT_FLAG_DIELECTRIC) != 0u;
 #define RT_LAUNCH_TRACE(F)                                                                        \
@@ -904,6 +1023,12 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
     case kFilterExact: RT_LAUNCH_TRACE(kFilterExact); break;
     case kFilterConservative: RT_LAUNCH_TRACE(kFilterConservative); break;
     case kFilterMatrix: RT_LAUNCH_TRACE(kFilterMatrix); break;
+    case kFilterBvh:
+        if (glass)
+            hipLaunchKernelGGL((trace_kernel<false, kFilterBvh, true>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((trace_kernel<false, kFilterBvh, false>), grid, block, lds, stream, a);
+        break;
     default:
         return hipErrorInvalidValue;
     }
@@ -913,6 +1038,9 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
 
 hipError_t trace_occupancy(int filter, size_t lds_bytes, int *workgroups_per_cu)
 {
+    if (filter == kFilterBvh)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            workgroups_per_cu, trace_kernel<false, kFilterBvh, false>, kTraceThreads, lds_bytes);
     if (filter == kFilterMatrix)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(
             workgroups_per_cu, trace_kernel<false, kFilterMatrix, false>, kTraceThreads, lds_bytes);

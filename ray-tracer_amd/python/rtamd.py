@@ -18,14 +18,14 @@ SPHERE_DTYPE = np.dtype(
 assert SPHERE_DTYPE.itemsize == 36
 
 MAT_GLASS, MAT_DIFFUSE, MAT_METAL, MAT_FUZZYMETAL = 0, 1, 2, 3
-OPT_FILTER, OPT_TILE_SPHERES, OPT_WORKGROUPS_PER_CU = 0, 1, 2
-FILTER_AUTO, FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX = -1, 0, 1, 2
+OPT_FILTER, OPT_TILE_SPHERES, OPT_WORKGROUPS_PER_CU, OPT_BVH_LEAF_SPHERES, OPT_BVH_MIN_SPHERES = 0, 1, 2, 3, 4
+FILTER_AUTO, FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX, FILTER_BVH = -1, 0, 1, 2, 3
 
 # every symbol include/rt_mi355x.h declares
 EXPORTS = [
     "rt_abi_version", "rt_status_string", "rt_last_error", "rt_create", "rt_destroy", "rt_set_scene",
     "rt_camera_init", "rt_render", "rt_render_progressive", "rt_render_device", "rt_accumulate_device", "rt_resolve_device",
-    "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_get_stats", "rt_reset_stats",
+    "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_accel_selfcheck", "rt_get_stats", "rt_reset_stats",
 ]
 
 
@@ -102,6 +102,7 @@ def load():
     L.rt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, vp]
     L.rt_accumulate_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, vp]
     L.rt_render_progressive.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, u32, PROGRESS_FN, vp]
+    L.rt_accel_selfcheck.argtypes = [vp, u32, i, C.POINTER(u32 * 4)]
     L.rt_resolve_device.argtypes = [vp, vp, u32, u32, u32, u32, i, i, i, i, vp, vp]
     L.rt_primary_hits.argtypes = [vp, C.POINTER(Camera), u32, u32, vp]
     L.rt_primary_hits_device.argtypes = [vp, C.POINTER(Camera), u32, u32, vp, vp]
@@ -144,6 +145,15 @@ PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)
 def params(width, height, spp, max_depth, seed=0, sample_begin=0, sample_count=0, tile_first=0, tile_stride=0,
            flags=0):
     return Params(width, height, spp, max_depth, seed, sample_begin, sample_count, tile_first, tile_stride, flags, 0)
+
+
+def accel_selfcheck(spheres, leaf_spheres=4):
+    """Host-only build + structural check of the hierarchy; returns (status, nodes, levels, large, records)."""
+    spheres = np.ascontiguousarray(spheres)
+    info = (C.c_uint32 * 4)()
+    st = load().rt_accel_selfcheck(spheres.ctypes.data if len(spheres) else None, len(spheres), leaf_spheres,
+                                   C.byref(info))
+    return (st,) + tuple(info)
 
 
 class Context:

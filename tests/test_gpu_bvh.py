@@ -1,0 +1,111 @@
+"""The box hierarchy (RT_OPT_FILTER 3) must select exactly the spheres the reference's brute-force
+loop (Source/main.cpp:534-546) selects: frames and ray counts bit-identical to the oracle, which
+tests every sphere."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle_lib as O
+import rtamd
+import scenes
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+C3_CAM = scenes.RANDOM_SPHERES_CAMERA
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = rtamd.Context(0)
+    c.set_option(rtamd.OPT_FILTER, rtamd.FILTER_BVH)
+    yield c
+    c.close()
+
+
+def same_as_oracle(ctx, sc, cam, W, H, spp, depth, seed, flags=0):
+    ctx.set_scene(sc)
+    ctx.reset_stats()
+    got = ctx.render(rtamd.make_camera(*cam), rtamd.params(W, H, spp, depth, seed=seed, flags=flags))
+    want, _, rays = O.trace_tile(sc, O.camera(*cam), W, H, spp, depth, O.RNG_COUNTER, seed=seed, flags=flags)
+    assert np.array_equal(got, want)
+    assert ctx.stats().rays == rays
+    return got
+
+
+@pytest.mark.parametrize("leaf", [1, 4, 15])
+def test_reference_scene_and_random_spheres(ctx, leaf):
+    ctx.set_option(rtamd.OPT_BVH_LEAF_SPHERES, leaf)
+    try:
+        same_as_oracle(ctx, rtamd.default_scene(), scenes.DEFAULT_CAMERA, 128, 72, 8, 10, 7)
+        sc = np.fromfile(os.path.join(G, "scene_c3_500.bin"), dtype=rtamd.SPHERE_DTYPE)
+        same_as_oracle(ctx, sc, C3_CAM, 160, 90, 4, 8, 1)
+        same_as_oracle(ctx, sc, C3_CAM, 96, 54, 4, 12, 3, flags=rtamd.FLAG_DIELECTRIC)  # rays from inside spheres
+    finally:
+        ctx.set_option(rtamd.OPT_BVH_LEAF_SPHERES, 4)
+
+
+def test_ten_thousand_spheres(ctx):
+    sc = scenes.random_spheres(10000, grid_half=50, seed=7)
+    same_as_oracle(ctx, sc, C3_CAM, 64, 36, 2, 8, 4)
+    same_as_oracle(ctx, sc, ((0.0, 30.0, 0.0), (5.0, 0.0, 5.0), (0.0, 0.0, 1.0), 60.0), 64, 36, 2, 8, 5)  # from above
+
+
+def test_coincident_and_nested_spheres_keep_the_tie_rule(ctx):
+    """Equal hit distance: the later sphere of the list wins (Source/main.cpp:492-499, 539-545),
+    wherever the hierarchy has put the two."""
+    rs = np.random.RandomState(5)
+    n = 64
+    sc = np.zeros(n, dtype=rtamd.SPHERE_DTYPE)
+    sc["center"] = rs.uniform(-4, 4, size=(n, 3)).astype(np.float32) + np.array([0, 0, -8], dtype=np.float32)
+    sc["radius"] = rs.uniform(0.3, 0.9, size=n).astype(np.float32)
+    sc["material"] = rtamd.MAT_DIFFUSE
+    sc["color"] = rs.uniform(0, 255, size=(n, 3)).astype(np.float32)
+    # exact duplicates at the two ends of the list, and concentric shells
+    sc[60], sc[61], sc[62], sc[63] = sc[3], sc[7], sc[3], sc[20]
+    sc["color"][60:] = rs.uniform(0, 255, size=(4, 3)).astype(np.float32)
+    sc[30]["center"], sc[30]["radius"] = sc[31]["center"], sc[31]["radius"] * 0.5
+    got = same_as_oracle(ctx, sc, scenes.DEFAULT_CAMERA, 160, 90, 3, 6, 9)
+    hits = O.primary_hits(sc, O.camera(*scenes.DEFAULT_CAMERA), 160, 90)
+    assert (hits == 62).any() and not (hits == 3).any() and not (hits == 60).any()
+    assert (got != 255).any()
+
+
+def test_rays_outside_the_filters_preconditions_take_the_exact_loop(ctx):
+    """NaN rays: the reference's comparisons are all false for them, so its loop accepts every
+    sphere in turn and the last one of the list wins (Source/main.cpp:481-499, 539-545) -- a walk
+    over boxes would find nothing.  Such rays must be scanned by the in-order loop instead."""
+    sc = scenes.random_spheres(200, grid_half=7, seed=2)
+    sc[-1]["material"], sc[-1]["color"] = rtamd.MAT_DIFFUSE, (200.0, 100.0, 50.0)
+    nan_cam = ((float("nan"), 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 20.0)
+    got = same_as_oracle(ctx, sc, nan_cam, 48, 27, 3, 6, 2)
+    assert (got != 255).any()  # not sky: the rays "hit"
+    # a camera far outside the 2^28 bound (its rays are too coarse to hit anything, like in the reference)
+    far = ((1.0e9, 2.0e8, 3.0e8), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 1.0e-6)
+    same_as_oracle(ctx, sc, far, 48, 27, 3, 6, 2)
+
+
+def test_scene_of_large_spheres_only_and_single_sphere(ctx):
+    sc = rtamd.default_scene()[[3]]  # one sphere: a single leaf under a root
+    same_as_oracle(ctx, sc, scenes.DEFAULT_CAMERA, 64, 36, 2, 6, 1)
+    two = rtamd.default_scene()[[1, 3]]
+    two[0]["radius"] = 0.01  # the other is 10^4 times larger: on the always-tested list
+    same_as_oracle(ctx, two, scenes.DEFAULT_CAMERA, 64, 36, 2, 6, 1)
+
+
+def test_clustered_scene_with_wide_radius_spread(ctx):
+    """Clusters far apart, radii over three decades: boxes of very different sizes, deep SAH splits."""
+    rs = np.random.RandomState(11)
+    n = 1500
+    sc = np.zeros(n, dtype=rtamd.SPHERE_DTYPE)
+    centres = rs.uniform(-60, 60, size=(12, 3))
+    which = rs.randint(0, 12, size=n)
+    sc["center"] = (centres[which] + rs.normal(0, 1.5, size=(n, 3))).astype(np.float32)
+    sc["radius"] = (10.0 ** rs.uniform(-2.5, 0.3, size=n)).astype(np.float32)
+    sc["material"] = rs.randint(0, 4, size=n)
+    sc["color"] = np.where((sc["material"] == 1)[:, None], rs.uniform(0, 255, (n, 3)), rs.uniform(0.2, 1, (n, 3)))
+    sc["fuzz"] = rs.uniform(0, 1, size=n)
+    cam = ((0.0, 20.0, 150.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0)
+    got = same_as_oracle(ctx, sc, cam, 128, 72, 3, 8, 6)
+    assert (got != got[0, 0]).any()

@@ -147,7 +147,7 @@ def test_frame_bit_exact_against_oracle(ctx, scene, cam, W, H, spp, depth, seed)
     assert ctx.stats().rays == rays
 
 
-@pytest.mark.parametrize("filt", [rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX])
+@pytest.mark.parametrize("filt", [rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX, rtamd.FILTER_BVH])
 def test_multi_tile_sphere_list_bit_exact(ctx, filt):
     """Sphere list longer than one LDS tile: two tiles of 128 plus a ragged one of 44."""
     sc = scenes.random_spheres(300, grid_half=9, seed=3)
@@ -168,16 +168,18 @@ def test_multi_tile_sphere_list_bit_exact(ctx, filt):
     assert np.array_equal(hits, O.primary_hits(sc, O.camera(*cam), 160, 90))
 
 
-def test_all_three_scans_agree(ctx):
-    """Unfused reference discriminant, fused vector filter and matrix-core filter: identical frames."""
+def test_all_scans_agree(ctx):
+    """Unfused reference discriminant, fused vector filter, matrix-core filter and box hierarchy:
+    identical frames."""
     ctx.set_scene(c3_scene())
     cam, p = rtamd.make_camera(*C3_CAM), rtamd.params(480, 270, 8, 8, seed=5)
     frames = []
-    for filt in (rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX):
+    for filt in (rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX, rtamd.FILTER_BVH):
         ctx.set_option(rtamd.OPT_FILTER, filt)
         frames.append(ctx.render(cam, p))
     ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
-    assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])
+    for f in frames[1:]:
+        assert np.array_equal(frames[0], f)
 
 
 def test_matrix_filter_on_a_four_sphere_scene(ctx):
@@ -208,10 +210,15 @@ def test_matrix_filter_far_from_origin_and_degenerate_paths(ctx):
     sc["fuzz"] = rs.uniform(0, 1, size=n)
     cam = ((5000.0, -3000.0, 4020.0), (5000.0, -3000.0, 4000.0), (0.0, 1.0, 0.0), 40.0)
     ctx.set_scene(sc)
-    ctx.reset_stats()
-    got = ctx.render(rtamd.make_camera(*cam), rtamd.params(96, 54, 6, 8, seed=12))
     want, _, rays = O.trace_tile(sc, O.camera(*cam), 96, 54, 6, 8, O.RNG_COUNTER, seed=12)
-    assert np.array_equal(got, want) and ctx.stats().rays == rays
+    try:
+        for filt in (rtamd.FILTER_MATRIX, rtamd.FILTER_BVH):
+            ctx.set_option(rtamd.OPT_FILTER, filt)
+            ctx.reset_stats()
+            got = ctx.render(rtamd.make_camera(*cam), rtamd.params(96, 54, 6, 8, seed=12))
+            assert np.array_equal(got, want) and ctx.stats().rays == rays
+    finally:
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
     assert (got != got[0, 0]).any()  # something was hit
 
 
@@ -325,7 +332,7 @@ def test_all_scans_agree_across_scene_scales(ctx, scale, offset):
     want, _, rays = O.trace_tile(sc, O.camera(*cam), 64, 36, 4, 6, O.RNG_COUNTER, seed=5)
     ctx.set_scene(sc)
     try:
-        for filt in (rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX):
+        for filt in (rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX, rtamd.FILTER_BVH):
             ctx.set_option(rtamd.OPT_FILTER, filt)
             ctx.reset_stats()
             got = ctx.render(rtamd.make_camera(*cam), rtamd.params(64, 36, 4, 6, seed=5))
