@@ -42,6 +42,8 @@ WORKLOADS = {
     "c4": (3840, 2160, 1024, 500, 11, "samples"),   # configs[3]: 1024 spp split over the GPUs
     "c5": (1920, 1080, 256, 10000, 50, "tiles"),    # configs[4]: 10k spheres, tile-partitioned
 }
+SCANS = {"auto": rtamd.FILTER_AUTO, "exact": rtamd.FILTER_EXACT, "vector": rtamd.FILTER_CONSERVATIVE,
+         "matrix": rtamd.FILTER_MATRIX, "hierarchy": rtamd.FILTER_BVH}
 FLOP_PER_TEST = 25.0          # miss path of RaySphereIntersectionTest, Source/main.cpp:475-479
 PEAK_FP32_TFLOPS = 157.3      # MI355X FP32, matrix (v_mfma_f32_*_f32) = vector: 256 CU x 128 FMA lanes x 2 x 2.4 GHz
 
@@ -93,6 +95,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--partition", choices=["samples", "tiles"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scan", choices=sorted(SCANS), default="auto",
+                    help="how rays find their candidate spheres (all give the same frame); auto = the library's choice")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,6 +118,10 @@ def main():
     ctx = rtamd.Context(local_rank)
     scene = scenes.random_spheres(N_SPHERES, grid_half=grid)
     ctx.set_scene(scene)
+    ctx.set_option(rtamd.OPT_FILTER, SCANS[args.scan])
+    scan = args.scan
+    if scan == "auto":  # the library's rule (rt_mi355x.h, RT_OPT_FILTER)
+        scan = "hierarchy" if N_SPHERES >= 64 else "vector"
     cam = rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA)
     total_spp = SPP * world if frame_spp is None else frame_spp
     p = dist_render.rank_params(W, H, total_spp, DEPTH, 1, args.partition, rank, world)
@@ -162,6 +170,25 @@ def main():
 
     st = ctx.stats()
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+    # The hierarchy skips most of the reference's ray-sphere tests, so its time says nothing about
+    # how well the FP32 pipe is used.  For that, the kernel that does perform every test (the
+    # matrix-core list scan) is timed beside it on rank 0, outside the timed region.
+    list_ms = None
+    if rank == 0 and scan == "hierarchy" and N_SPHERES <= 2000:
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_MATRIX)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tracer.accumulate(p, d_sums)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3):
+            tracer.accumulate(p, d_sums)
+        e1.record()
+        torch.cuda.synchronize()
+        list_ms = e0.elapsed_time(e1) / 3.0
+        ctx.set_option(rtamd.OPT_FILTER, SCANS[args.scan])
+    if world > 1:
+        dist.barrier()
     t = torch.tensor([elapsed, float(st.rays), float(st.wave_passes), kernel_ms], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = t.clone()
@@ -180,9 +207,9 @@ def main():
         achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "c3":
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch", {}).get(scan)
             except Exception:
                 traffic = None
         line = {
@@ -203,7 +230,7 @@ def main():
                              "c4": "random-spheres scene, 500 spheres, 3840x2160, 1024 spp per frame, max depth 8 (BASELINE configs[3])",
                              "c5": "random-spheres scene, 10000 spheres, 1920x1080, 256 spp per frame, max depth 8 (BASELINE configs[4])"}[args.workload],
                 "spheres": N_SPHERES, "width": W, "height": H, "frame_spp": total_spp,
-                "max_depth": DEPTH, "partition": args.partition,
+                "max_depth": DEPTH, "partition": args.partition, "scan": scan,
                 "collective": "reduce(sum,int32,%d) to rank 0" % (W * H * 3) if world > 1 else "none",
             },
             "rays_per_step": total_rays / args.steps,
@@ -215,8 +242,16 @@ def main():
                 "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                 "flop_per_unit": "25 flop per ray-sphere test x %d spheres per ray" % N_SPHERES,
+                "kernel": "trace_kernel, %s scan" % scan,
             },
         }
+        if scan == "hierarchy":
+            line["roofline"]["note"] = ("algorithmic work = the reference's brute-force tests; the hierarchy skips most of "
+                                        "them, so frac can exceed 1 -- see list_scan for the kernel that performs them all")
+            if list_ms:
+                a_list = flop_per_launch / (list_ms * 1e-3) / 1e12
+                line["roofline"]["list_scan"] = {"kernel": "trace_kernel, matrix scan", "kernel_ms": list_ms,
+                                                 "achieved": a_list, "frac": a_list / PEAK_FP32_TFLOPS}
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             line["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(line), flush=True)

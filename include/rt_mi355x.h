@@ -196,7 +196,8 @@ typedef enum rt_option {
     RT_OPT_TILE_SPHERES = 1,      /* spheres per LDS tile, 128..4096 (default 512) */
     RT_OPT_WORKGROUPS_PER_CU = 2, /* cap on resident workgroups per CU, 0 = occupancy limit */
     RT_OPT_BVH_LEAF_SPHERES = 3,  /* most spheres per leaf of the hierarchy, 1..15 (default 4) */
-    RT_OPT_BVH_MIN_SPHERES = 4    /* scene size from which the automatic choice is the hierarchy */
+    RT_OPT_BVH_MIN_SPHERES = 4,   /* scene size from which the automatic choice is the hierarchy */
+    RT_OPT_BVH_LDS_NODES = 5      /* hierarchies of up to this many nodes are walked in LDS, 0..2048 (default 512) */
 } rt_option;
 
 int rt_set_option(rt_context *ctx, int option, int64_t value);

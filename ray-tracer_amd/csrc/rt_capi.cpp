@@ -44,7 +44,8 @@ struct rt_context {
     BvhHost bvh;                   // without the node / record arrays once they are on the device
     bool bvh_ready = false;
     int bvh_leaf_max = 4;
-    uint32_t bvh_auto_min = 1024;  // automatic choice: hierarchy from this many spheres up
+    uint32_t bvh_lds_nodes_max = 512; // trees up to this many nodes (64 B each) are walked in LDS
+    uint32_t bvh_auto_min = 64;    // automatic choice: hierarchy from this many spheres up (measured crossover)
     float4 *d_bvh_nodes = nullptr;
     Geom *d_bvh_geom = nullptr;
     uint32_t *d_bvh_index = nullptr;
@@ -210,7 +211,8 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
         a.bvh.leaf_index = ctx->d_bvh_index;
         a.bvh.n_nodes = (uint32_t)b.nodes.size();
         a.bvh.n_large = b.n_large;
-        a.bvh.levels = b.levels;
+        a.bvh.levels = b.levels ? b.levels : 1u;
+        a.bvh.lds_nodes = a.bvh.n_nodes <= ctx->bvh_lds_nodes_max ? a.bvh.n_nodes : 0u;
         memcpy(a.bvh.center, b.center, sizeof a.bvh.center);
         a.bvh.radius = b.radius;
         a.bvh.rmin = b.rmin;
@@ -252,7 +254,7 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     a.tile_cap = n_pad <= ctx->tile_cap_max ? (n_pad ? n_pad : kPad) : ctx->tile_cap_max;
     if (a.filter == kFilterBvh)
         a.tile_cap = 0u; // the walk reads nodes and leaf records from memory
-    a.aux_bytes = trace_aux_bytes(a.filter, a.bvh.levels);
+    a.aux_bytes = trace_aux_bytes(a.filter, a.bvh.levels, a.bvh.lds_nodes);
 
     const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth);
     if (lds > 160u * 1024u)
@@ -755,6 +757,11 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
             drop_bvh(ctx);
             ctx->bvh_leaf_max = (int)value;
         }
+        return RT_OK;
+    case RT_OPT_BVH_LDS_NODES:
+        if (value < 0 || value > 2048)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_LDS_NODES takes 0..2048");
+        ctx->bvh_lds_nodes_max = (uint32_t)value;
         return RT_OK;
     case RT_OPT_BVH_MIN_SPHERES:
         if (value < 1 || value > (1ll << 30))

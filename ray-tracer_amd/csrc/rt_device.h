@@ -37,7 +37,8 @@ struct BvhArgs {
     const Geom *leaf_geom;      // n_large always-tested records, then the leaves' records
     const uint32_t *leaf_index; // list index of each record
     uint32_t n_nodes, n_large;
-    uint32_t levels;            // traversal stack entries per ray
+    uint32_t levels;            // traversal stack entries per ray (>= 1)
+    uint32_t lds_nodes;         // n_nodes if the kernel keeps the nodes in LDS, else 0
     float center[3];            // origin of the boxes' coordinates
     float radius, rmin, rmin2w; // see BvhHost
 };
@@ -93,7 +94,7 @@ struct IntersectArgs {
 };
 
 // Bytes of LDS between the tiles and the bounce stack for `filter`.
-uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels);
+uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels, uint32_t bvh_lds_nodes);
 // Bytes of dynamic LDS the trace kernel needs.
 size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth);
 

@@ -64,8 +64,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // word to [0,1): float(w) / 2^32, and 1.0f replaced by the float below it.
 __device__ __forceinline__ float unit_float(uint32_t w)
 {
-    const float r = (float)w * 0x1p-32f;
-    return r >= 1.0f ? 0.99999994f : r;
+    return fminf((float)w * 0x1p-32f, 0.99999994f);
 }
 
 // RandomFloat(-1.0f, 1.0f), Source/main.cpp:94-97: -1 + 2*r evaluated in double, then
@@ -80,12 +79,16 @@ __device__ __forceinline__ float range_m1_p1(uint32_t w)
 // Bytes
 // ---------------------------------------------------------------------------
 
-// static_cast<int>(float) as the reference's x86-64 build executes it: truncate,
-// INT_MIN for NaN and out-of-range; then glm::clamp to 0..255 (Source/main.cpp:117-133).
+// static_cast<int>(float) as the reference's x86-64 build executes it (cvttss2si: truncate,
+// INT_MIN for NaN and out-of-range), then glm::clamp to 0..255 (Source/main.cpp:117-133).
+// INT_MIN clamps to 0, so the result is 0 for NaN, for v < 1 and for v >= 2^31, else
+// min(trunc(v), 255).  v_cvt_u32_f32 truncates and saturates (NaN and negatives to 0, large
+// values to 0xFFFFFFFF); read as signed, everything from 2^31 up is negative and clamps to 0.
 __device__ __forceinline__ int to_byte(float v)
 {
-    const int iv = (v < 2147483648.0f && v >= -2147483648.0f) ? (int)v : INT_MIN;
-    return min(max(iv, 0), 255);
+    uint32_t u;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(v));
+    return min(max((int)u, 0), 255);
 }
 
 // GetGradientColorAtRay + Lerp, Source/main.cpp:461-467, 157-160.
@@ -301,6 +304,27 @@ __device__ __forceinline__ void resolve_unordered(const RayState &r, const Geom 
     }
 }
 
+// resolve_unordered with the list index fetched only when the root is in range.
+__device__ __forceinline__ void resolve_leaf(const RayState &r, const Geom &s, const uint32_t *index, float tmin,
+                                             float &closest, int &best)
+{
+    float B;
+    const float disc = discriminant(r, s, B);
+    if (disc < 0.0f)
+        return;
+    const float sq = sqrtf(disc);
+    float root = (-B - sq) / r.two_a;
+    if (root < tmin)
+        root = (-B + sq) / r.two_a;
+    if (root >= tmin && root <= closest) {
+        const int idx = (int)*index;
+        if (root < closest || idx > best) {
+            closest = root;
+            best = idx;
+        }
+    }
+}
+
 // Publishes every lane's ray in matrix-operand form through the wave's LDS
 // staging area (9 x 64 floats) and reads back this lane's B/C elements.
 __device__ __forceinline__ void matrix_operands(const RayState &r, bool use, float tx, float ty, float tz,
@@ -438,8 +462,9 @@ __device__ __forceinline__ void scan_tile_matrix(const float *__restrict__ filt,
 // cover.  A direction component too small to divide by is replaced by
 // 2^-50 of the largest one: over any distance inside the tree that moves the ray
 // by less than 2^-49 of the tree's size.  Only tame rays walk the tree.
-__device__ __forceinline__ void bvh_closest_hit(const BvhArgs &b, const RayState &r, uint32_t *stk, float tmin,
-                                                float &closest, int &best)
+template <bool NODES_IN_LDS>
+__device__ __forceinline__ void bvh_closest_hit(const BvhArgs &b, const float4 *lds_nodes, const RayState &r,
+                                                uint32_t *stk, float tmin, float &closest, int &best)
 {
     for (uint32_t i = 0; i < b.n_large; ++i)
         resolve_unordered(r, b.leaf_geom[i], (int)b.leaf_index[i], tmin, closest, best);
@@ -460,6 +485,16 @@ __device__ __forceinline__ void bvh_closest_hit(const BvhArgs &b, const RayState
     // t at plane p: (p - o) / d = fma(p, i, n); lower planes are moved by -pad, upper by +pad
     const float nlx = -((ox + pad) * ix), nly = -((oy + pad) * iy), nlz = -((oz + pad) * iz);
     const float nhx = -((ox - pad) * ix), nhy = -((oy - pad) * iy), nhz = -((oz - pad) * iz);
+    // Which of the two planes of an axis the ray meets first depends on the sign of d.  Instead
+    // of min/max per box (half-rate instructions), each t is fma(lo, a, fma(hi, b, c)) with one
+    // of a, b zero: the same single rounding, on full-rate instructions only.
+    const bool px = ix >= 0.0f, py = iy >= 0.0f, pz = iz >= 0.0f;
+    const float nax = px ? ix : 0.0f, nbx = px ? 0.0f : ix, ncx = px ? nlx : nhx; // entry plane
+    const float fax = px ? 0.0f : ix, fbx = px ? ix : 0.0f, fcx = px ? nhx : nlx; // exit plane
+    const float nay = py ? iy : 0.0f, nby = py ? 0.0f : iy, ncy = py ? nly : nhy;
+    const float fay = py ? 0.0f : iy, fby = py ? iy : 0.0f, fcy = py ? nhy : nly;
+    const float naz = pz ? iz : 0.0f, nbz = pz ? 0.0f : iz, ncz = pz ? nlz : nhz;
+    const float faz = pz ? 0.0f : iz, fbz = pz ? iz : 0.0f, fcz = pz ? nhz : nlz;
     const float t_lo = tmin * (1.0f - 0x1p-20f);
     float t_hi = closest * (1.0f + 0x1p-20f);
 
@@ -468,21 +503,18 @@ __device__ __forceinline__ void bvh_closest_hit(const BvhArgs &b, const RayState
     uint32_t sp = 0u;
     for (;;) {
         while (node >= 0) {
-            const float4 *np = b.nodes + (size_t)node * 4u;
+            const float4 *np = (NODES_IN_LDS ? lds_nodes : b.nodes) + (size_t)node * 4u;
             const float4 l0 = np[0], h0 = np[1], l1 = np[2], h1 = np[3];
-            float a0, a1, n0, n1, f0, f1;
-            a0 = __builtin_fmaf(l0.x, ix, nlx); a1 = __builtin_fmaf(h0.x, ix, nhx);
-            n0 = fminf(a0, a1); f0 = fmaxf(a0, a1);
-            a0 = __builtin_fmaf(l0.y, iy, nly); a1 = __builtin_fmaf(h0.y, iy, nhy);
-            n0 = fmaxf(n0, fminf(a0, a1)); f0 = fminf(f0, fmaxf(a0, a1));
-            a0 = __builtin_fmaf(l0.z, iz, nlz); a1 = __builtin_fmaf(h0.z, iz, nhz);
-            n0 = fmaxf(fmaxf(n0, fminf(a0, a1)), t_lo); f0 = fminf(fminf(f0, fmaxf(a0, a1)), t_hi);
-            a0 = __builtin_fmaf(l1.x, ix, nlx); a1 = __builtin_fmaf(h1.x, ix, nhx);
-            n1 = fminf(a0, a1); f1 = fmaxf(a0, a1);
-            a0 = __builtin_fmaf(l1.y, iy, nly); a1 = __builtin_fmaf(h1.y, iy, nhy);
-            n1 = fmaxf(n1, fminf(a0, a1)); f1 = fminf(f1, fmaxf(a0, a1));
-            a0 = __builtin_fmaf(l1.z, iz, nlz); a1 = __builtin_fmaf(h1.z, iz, nhz);
-            n1 = fmaxf(fmaxf(n1, fminf(a0, a1)), t_lo); f1 = fminf(fminf(f1, fmaxf(a0, a1)), t_hi);
+#define RT_SLAB(lo, hi, na, nb, nc) __builtin_fmaf(lo, na, __builtin_fmaf(hi, nb, nc))
+            const float n0 = fmaxf(fmaxf(fmaxf(RT_SLAB(l0.x, h0.x, nax, nbx, ncx), RT_SLAB(l0.y, h0.y, nay, nby, ncy)),
+                                         RT_SLAB(l0.z, h0.z, naz, nbz, ncz)), t_lo);
+            const float f0 = fminf(fminf(fminf(RT_SLAB(l0.x, h0.x, fax, fbx, fcx), RT_SLAB(l0.y, h0.y, fay, fby, fcy)),
+                                         RT_SLAB(l0.z, h0.z, faz, fbz, fcz)), t_hi);
+            const float n1 = fmaxf(fmaxf(fmaxf(RT_SLAB(l1.x, h1.x, nax, nbx, ncx), RT_SLAB(l1.y, h1.y, nay, nby, ncy)),
+                                         RT_SLAB(l1.z, h1.z, naz, nbz, ncz)), t_lo);
+            const float f1 = fminf(fminf(fminf(RT_SLAB(l1.x, h1.x, fax, fbx, fcx), RT_SLAB(l1.y, h1.y, fay, fby, fcy)),
+                                         RT_SLAB(l1.z, h1.z, faz, fbz, fcz)), t_hi);
+#undef RT_SLAB
             const bool hit0 = n0 <= f0, hit1 = n1 <= f1;
             const int c0 = __float_as_int(l0.w), c1 = __float_as_int(h0.w);
             if (hit0 && hit1) {
@@ -504,8 +536,18 @@ __device__ __forceinline__ void bvh_closest_hit(const BvhArgs &b, const RayState
         if (node == kDone)
             break;
         const uint32_t code = (uint32_t)~node, first = code >> 4, count = code & 15u;
-        for (uint32_t i = first; i < first + count; ++i)
-            resolve_unordered(r, b.leaf_geom[i], (int)b.leaf_index[i], tmin, closest, best);
+        for (uint32_t i0 = 0u; i0 < count; i0 += 4u) {
+            // up to four records in flight before the first is used
+            Geom g[4];
+#pragma unroll
+            for (uint32_t j = 0u; j < 4u; ++j)
+                if (i0 + j < count)
+                    g[j] = b.leaf_geom[first + i0 + j];
+#pragma unroll
+            for (uint32_t j = 0u; j < 4u; ++j)
+                if (i0 + j < count)
+                    resolve_leaf(r, g[j], b.leaf_index + (first + i0 + j), tmin, closest, best);
+        }
         t_hi = closest * (1.0f + 0x1p-20f);
         if (sp == 0u)
             break;
@@ -599,6 +641,13 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
 
     if (!MULTI_TILE && FILTER != kFilterBvh) {
         load_tile(tile_f, tile_e, filt_src, a.exact, 0u, n_pad);
+        __syncthreads();
+    }
+    // hierarchy scan: the nodes of a small tree live in LDS, behind the walk's stack
+    float4 *bvh_lds = reinterpret_cast<float4 *>(stage) + (size_t)a.bvh.levels * (kTraceThreads / 4);
+    if (FILTER == kFilterBvh && a.bvh.lds_nodes) {
+        for (uint32_t i = threadIdx.x; i < a.bvh.lds_nodes * 4u; i += blockDim.x)
+            bvh_lds[i] = a.bvh.nodes[i];
         __syncthreads();
     }
 
@@ -703,8 +752,13 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
             matrix_operands(ray, mine, a.shift[0], a.shift[1], a.shift[2], stage + wave * (9 * 64), lane, mo);
         if (FILTER == kFilterBvh) {
             if (active) {
-                if (ray.tame)
-                    bvh_closest_hit(a.bvh, ray, reinterpret_cast<uint32_t *>(stage) + tid, 0.001f, closest, best);
+                if (ray.tame) {
+                    uint32_t *stk = reinterpret_cast<uint32_t *>(stage) + tid;
+                    if (a.bvh.lds_nodes)
+                        bvh_closest_hit<true>(a.bvh, bvh_lds, ray, stk, 0.001f, closest, best);
+                    else
+                        bvh_closest_hit<false>(a.bvh, nullptr, ray, stk, 0.001f, closest, best);
+                }
                 else // the reference's in-order loop over the whole list, from memory
                     scan_tile<kFilterExact>(a.exact, a.exact, a.n, 0u, ray, 0.001f, closest, best);
             }
@@ -987,10 +1041,10 @@ __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, u
 // Launch wrappers
 // ---------------------------------------------------------------------------
 
-uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels)
+uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels, uint32_t bvh_lds_nodes)
 {
     if (filter == kFilterBvh)
-        return (bvh_levels ? bvh_levels : 1u) * kTraceThreads * (uint32_t)sizeof(uint32_t);
+        return (bvh_levels ? bvh_levels : 1u) * kTraceThreads * (uint32_t)sizeof(uint32_t) + bvh_lds_nodes * 64u;
     return 4u * 9u * 64u * (uint32_t)sizeof(float);
 }
 

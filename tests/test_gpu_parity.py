@@ -297,6 +297,23 @@ def test_edge_cases(ctx):
     assert (got[18, 10] == 255).all()  # the glass sphere is flat white
 
 
+def test_colour_conversion_extremes(ctx):
+    """ToRGB(vec3) on values outside int range (Source/main.cpp:117-133): the reference's float ->
+    int conversion yields INT_MIN for NaN and for anything from 2^31 up, which clamps to 0, not 255."""
+    sc = rtamd.default_scene()
+    sc["material"] = rtamd.MAT_METAL
+    sc["fuzz"] = 0.0
+    sc[0]["color"] = (1e38, np.inf, np.nan)
+    sc[1]["color"] = (-1.0, 8421504.0, 8421505.0)        # 255 * c straddles 2^31
+    sc[2]["color"] = (16843009.0, 0.99999994, 1.0000001)  # 255 * c = 2^32 + ...; just below / above 255
+    sc[3]["color"] = (3.5, 0.0, -0.0)
+    ctx.set_scene(sc)
+    got = ctx.render(rtamd.default_camera(), rtamd.params(96, 54, 4, 6, seed=4))
+    want, _, _ = O.trace_tile(sc, O.default_camera(), 96, 54, 4, 6, O.RNG_COUNTER, seed=4)
+    assert np.array_equal(got, want)
+    assert (got[27, 20] == 0).all()  # left sphere: 1e38 * c, inf * c, nan * c all end as 0
+
+
 def test_error_paths(ctx):
     fresh = rtamd.Context(0)
     cam, p = rtamd.default_camera(), rtamd.params(8, 8, 1, 1)

@@ -32,6 +32,26 @@ KERNEL(k_and_or, "v_and_or_b32 %0, %0, %1, %2")
 KERNEL(k_max3, "v_max3_f32 %0, %0, %1, %2")
 KERNEL(k_cvt, "v_cvt_f32_u32 %0, %0")
 KERNEL(k_cmp, "v_cmp_lt_f32 vcc, %0, %1")
+KERNEL(k_min, "v_min_f32 %0, %0, %1")
+KERNEL(k_max, "v_max_f32 %0, %0, %1")
+KERNEL(k_mul, "v_mul_f32 %0, %0, %1")
+KERNEL(k_sub, "v_sub_f32 %0, %0, %1")
+KERNEL(k_min3, "v_min3_f32 %0, %0, %1, %2")
+KERNEL(k_med3, "v_med3_f32 %0, %0, %1, %2")
+KERNEL(k_cndmask64, "v_cndmask_b32_e64 %0, %0, %1, s[10:11]")
+KERNEL(k_lshl_add, "v_lshl_add_u32 %0, %0, 1, %1")
+KERNEL(k_mad_u64, "v_mad_u64_u32 v[20:21], vcc, %0, %1, v[20:21]")
+KERNEL(k_perm, "v_perm_b32 %0, %0, %1, %2")
+KERNEL(k_cvt_ub, "v_cvt_f32_ubyte1 %0, %0")
+KERNEL(k_bfi, "v_bfi_b32 %0, %0, %1, %2")
+KERNEL(k_pk_fma, "v_pk_fma_f32 v[20:21], v[20:21], v[22:23], v[24:25]")
+KERNEL(k_pk_mul, "v_pk_mul_f32 v[20:21], v[20:21], v[22:23]")
+KERNEL(k_mov, "v_mov_b32 %0, %1")
+KERNEL(k_lshlrev, "v_lshlrev_b32 %0, 1, %0")
+KERNEL(k_and, "v_and_b32 %0, %0, %1")
+KERNEL(k_xor3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+KERNEL(k_add3, "v_add3_u32 %0, %0, %1, %2")
+KERNEL(k_fmac, "v_fmac_f32 %0, %1, %2")
 
 typedef void (*kern_t)(unsigned *, unsigned, unsigned, int, unsigned long long *);
 
@@ -57,5 +77,8 @@ int main()
 #define RUN(K) run(#K, K, d, dclk)
     RUN(k_fma); RUN(k_alignbit); RUN(k_lshl_or); RUN(k_cndmask); RUN(k_add); RUN(k_xor); RUN(k_mullo); RUN(k_mulhi);
     RUN(k_sqrt); RUN(k_rcp); RUN(k_bfe); RUN(k_and_or); RUN(k_max3); RUN(k_cvt); RUN(k_cmp);
+    RUN(k_min); RUN(k_max); RUN(k_mul); RUN(k_sub); RUN(k_min3); RUN(k_med3); RUN(k_cndmask64); RUN(k_lshl_add);
+    RUN(k_mad_u64); RUN(k_perm); RUN(k_cvt_ub); RUN(k_bfi); RUN(k_pk_fma); RUN(k_pk_mul); RUN(k_mov); RUN(k_lshlrev);
+    RUN(k_and); RUN(k_xor3); RUN(k_add3); RUN(k_fmac);
     return 0;
 }
