@@ -304,14 +304,26 @@ __device__ __forceinline__ void resolve_unordered(const RayState &r, const Geom 
     }
 }
 
-// resolve_unordered with the list index fetched only when the root is in range.
-__device__ __forceinline__ void resolve_leaf(const RayState &r, const Geom &s, const uint32_t *index, float tmin,
-                                             float &closest, int &best)
+// First half of resolve_unordered for a leaf record: the discriminant, and whether the root
+// evaluation can be skipped.  Besides the reference's own `Discriminant < 0` early-out, a sphere
+// with B > 0 and C > 0 (origin outside, centre behind) is dropped without a square root: then
+// 4AC > 0, so fl(B*B - 4AC) <= fl(B*B), its correctly rounded root is at most sqrt(fl(B*B)) = |B|,
+// both numerators -B -+ sq are <= 0 and the reference rejects both roots against tmin > 0.
+__device__ __forceinline__ bool leaf_candidate(const RayState &r, const Geom &s, float &B, float &disc)
 {
-    float B;
-    const float disc = discriminant(r, s, B);
-    if (disc < 0.0f)
-        return;
+    const float ocx = r.ox - s.cx, ocy = r.oy - s.cy, ocz = r.oz - s.cz;
+    const float d = ocx * r.dx + ocy * r.dy + ocz * r.dz;
+    B = d + d;
+    const float C = (ocx * ocx + ocy * ocy + ocz * ocz) - s.r2;
+    disc = B * B - r.four_a * C;
+    return !(disc < 0.0f) && !(B > 0.0f && C > 0.0f);
+}
+
+// Second half: the effective root (Source/main.cpp:490-499) and the closest-hit update; the
+// list index is fetched only when the root is in range.
+__device__ __forceinline__ void leaf_root(const RayState &r, float B, float disc, const uint32_t *index, float tmin,
+                                          float &closest, int &best)
+{
     const float sq = sqrtf(disc);
     float root = (-B - sq) / r.two_a;
     if (root < tmin)
@@ -537,16 +549,29 @@ __device__ __forceinline__ void bvh_closest_hit(const BvhArgs &b, const float4 *
             break;
         const uint32_t code = (uint32_t)~node, first = code >> 4, count = code & 15u;
         for (uint32_t i0 = 0u; i0 < count; i0 += 4u) {
-            // up to four records in flight before the first is used
+            // up to four records in flight before the first is used; then every lane walks its
+            // own candidates, so the wave pays for the most candidates any lane has, not for
+            // every record some lane hits
             Geom g[4];
 #pragma unroll
             for (uint32_t j = 0u; j < 4u; ++j)
                 if (i0 + j < count)
                     g[j] = b.leaf_geom[first + i0 + j];
+            float Bj[4], dj[4];
+            uint32_t cand = 0u;
 #pragma unroll
-            for (uint32_t j = 0u; j < 4u; ++j)
-                if (i0 + j < count)
-                    resolve_leaf(r, g[j], b.leaf_index + (first + i0 + j), tmin, closest, best);
+            for (uint32_t j = 0u; j < 4u; ++j) {
+                Bj[j] = dj[j] = 0.0f;
+                if (i0 + j < count && leaf_candidate(r, g[j], Bj[j], dj[j]))
+                    cand |= 1u << j;
+            }
+            while (cand != 0u) {
+                const uint32_t j = (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1u;
+                const float Bs = j == 0u ? Bj[0] : j == 1u ? Bj[1] : j == 2u ? Bj[2] : Bj[3];
+                const float ds = j == 0u ? dj[0] : j == 1u ? dj[1] : j == 2u ? dj[2] : dj[3];
+                leaf_root(r, Bs, ds, b.leaf_index + (first + i0 + j), tmin, closest, best);
+            }
         }
         t_hi = closest * (1.0f + 0x1p-20f);
         if (sp == 0u)
