@@ -44,6 +44,7 @@ struct rt_context {
     BvhHost bvh;                   // without the node / record arrays once they are on the device
     bool bvh_ready = false;
     int bvh_leaf_max = 4;
+    uint32_t bvh_suspend_lanes = 16;  // see RT_OPT_BVH_SUSPEND_LANES
     uint32_t bvh_lds_nodes_max = 512; // trees up to this many nodes (64 B each) are walked in LDS
     uint32_t bvh_auto_min = 64;    // automatic choice: hierarchy from this many spheres up (measured crossover)
     float4 *d_bvh_nodes = nullptr;
@@ -213,8 +214,9 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
         a.bvh.n_large = b.n_large;
         a.bvh.levels = b.levels ? b.levels : 1u;
         a.bvh.lds_nodes = a.bvh.n_nodes <= ctx->bvh_lds_nodes_max ? a.bvh.n_nodes : 0u;
+        a.bvh.suspend_lanes = ctx->bvh_suspend_lanes;
         memcpy(a.bvh.center, b.center, sizeof a.bvh.center);
-        a.bvh.radius = b.radius;
+        a.bvh.radius2 = std::nextafter(b.radius * b.radius, INFINITY);
         a.bvh.rmin = b.rmin;
         a.bvh.rmin2w = b.rmin2w;
     }
@@ -762,6 +764,11 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
         if (value < 0 || value > 2048)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_LDS_NODES takes 0..2048");
         ctx->bvh_lds_nodes_max = (uint32_t)value;
+        return RT_OK;
+    case RT_OPT_BVH_SUSPEND_LANES:
+        if (value < 0 || value > 63)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_SUSPEND_LANES takes 0..63");
+        ctx->bvh_suspend_lanes = (uint32_t)value;
         return RT_OK;
     case RT_OPT_BVH_MIN_SPHERES:
         if (value < 1 || value > (1ll << 30))

@@ -39,8 +39,9 @@ struct BvhArgs {
     uint32_t n_nodes, n_large;
     uint32_t levels;            // traversal stack entries per ray (>= 1)
     uint32_t lds_nodes;         // n_nodes if the kernel keeps the nodes in LDS, else 0
+    uint32_t suspend_lanes;     // a wave leaves the walk when at most this many lanes are still in it
     float center[3];            // origin of the boxes' coordinates
-    float radius, rmin, rmin2w; // see BvhHost
+    float radius2, rmin, rmin2w; // see BvhHost (radius2 >= radius^2)
 };
 
 struct TraceArgs {

@@ -123,11 +123,11 @@ __device__ __forceinline__ void ray_prepare(RayState &r)
     r.four_a = 4.0f * A;
     r.two_a = 2.0f * A;
     r.a_filter = __builtin_fmaf(-0x1p-17f, A, A);
-    const float m = fmaxf(fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fmaxf(fabsf(r.oz), fabsf(r.dx))),
-                          fmaxf(fabsf(r.dy), fabsf(r.dz)));
-    // comparisons are false for NaN, so a NaN anywhere makes the ray not tame
-    r.tame = (m < kTameMax) && (A >= kTameMinA) && (r.ox == r.ox) && (r.oy == r.oy) && (r.oz == r.oz) &&
-             (r.dx == r.dx) && (r.dy == r.dy) && (r.dz == r.dz);
+    // the sum of magnitudes is NaN or Inf as soon as one component is, and comparisons with NaN
+    // are false: one test covers "finite" and "small enough" (it is a little stricter than a test
+    // per component, which only sends a few more rays to the exact scan)
+    const float m = ((fabsf(r.ox) + fabsf(r.oy)) + (fabsf(r.oz) + fabsf(r.dx))) + (fabsf(r.dy) + fabsf(r.dz));
+    r.tame = (m < kTameMax) && (A >= kTameMinA);
 }
 
 // Camera::GetRay, Source/main.cpp:440-444, for pixel (i, j) with jitter (ju, jv)
@@ -469,24 +469,51 @@ __device__ __forceinline__ void scan_tile_matrix(const float *__restrict__ filt,
 //     pad >= sqrt(rmin^2 (1 + 64u) + 64u qmax) - rmin,   qmax = (|O - center| + radius)^2 >= q.
 // The slab test runs in coordinates relative to the tree's centre; its own
 // roundings move a plane by less than 8u (|O - center| + radius) and scale a t by
-// less than 1 + 4u, which the extra 32u (|O - center| + radius) + 8u r_eff of padding,
-// the factor 1.001 on the whole and the 2^-20 relative slack on [tmin, closest]
-// cover.  A direction component too small to divide by is replaced by
+// less than 1 + 4u, which an extra 2^-10 r_eff of padding (r_eff^2 >= 64u qmax, so
+// this exceeds 2^-1 sqrt(u qmax) = 2^11 u sqrt(qmax)), the factor 1.001 on the whole
+// and the 2^-20 relative slack on [tmin, closest] cover.  A direction component too small to divide by is replaced by
 // 2^-50 of the largest one: over any distance inside the tree that moves the ray
 // by less than 2^-49 of the tree's size.  Only tame rays walk the tree.
-template <bool NODES_IN_LDS>
-__device__ __forceinline__ void bvh_closest_hit(const BvhArgs &b, const float4 *lds_nodes, const RayState &r,
-                                                uint32_t *stk, float tmin, float &closest, int &best)
+// The walk is resumable.  Its per-ray state is (node, sp, closest, best) plus the ray's stack
+// column in LDS; a wave stops walking when no more than `suspend` of its lanes are still at it
+// (unless that was already so when it started), the finished rays go on to shading, and the
+// stragglers pick their walk up again in the wave's next pass, next to freshly started rays.
+// That cuts the tail of iterations a wave would spend with a handful of lanes active.
+// node: >= 0 inner node to visit, negative leaf code to process, kBvhDone when finished.
+constexpr int kBvhDone = INT_MIN;
+
+// Start of a ray's walk: the always-tested spheres, then the root.
+__device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, float tmin, int &node, uint32_t &sp,
+                                          float &closest, int &best)
 {
+    closest = INFINITY;
+    best = -1;
     for (uint32_t i = 0; i < b.n_large; ++i)
         resolve_unordered(r, b.leaf_geom[i], (int)b.leaf_index[i], tmin, closest, best);
-    if (b.n_nodes == 0u)
+    node = b.n_nodes ? 0 : kBvhDone;
+    sp = 0u;
+}
+
+// Must be called by all 64 lanes; `walking` lanes hold a tame ray whose node is not kBvhDone.
+template <bool NODES_IN_LDS>
+__device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nodes, const RayState &r,
+                                         uint32_t *stk, bool walking, float tmin, int &node, uint32_t &sp,
+                                         float &closest, int &best)
+{
+    if (!walking)
+        node = kBvhDone;
+    const uint32_t n_start = (uint32_t)__popcll(__ballot(walking));
+    if (n_start == 0u)
         return;
+    const uint32_t suspend = n_start > b.suspend_lanes ? b.suspend_lanes : 0u;
 
     const float ox = r.ox - b.center[0], oy = r.oy - b.center[1], oz = r.oz - b.center[2];
-    const float reach = (sqrtf(__builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox))) + b.radius) * (1.0f + 0x1p-20f);
-    const float reff = sqrtf(__builtin_fmaf(reach * reach, 0x1p-18f, b.rmin2w));
-    const float pad = ((reff - b.rmin) + __builtin_fmaf(reach, 0x1p-19f, reff * 0x1p-21f)) * 1.001f;
+    // reach^2 = (|o| + radius)^2 <= 2 (|o|^2 + radius^2); the hardware square root (1 ulp) is
+    // inside the 1.001.  Since reff^2 >= 2^-18 reach^2, the slab roundings' 40u reach is below
+    // 2^-10 reff.
+    const float reach2 = 2.0f * __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, __builtin_fmaf(ox, ox, b.radius2)));
+    const float reff = __builtin_amdgcn_sqrtf(__builtin_fmaf(reach2, 0x1p-18f * (1.0f + 0x1p-10f), b.rmin2w));
+    const float pad = __builtin_fmaf(reff, 0x1.01p-10f, reff - b.rmin) * 1.001f;
 
     const float dmax = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz));
     const float dlim = dmax * 0x1p-50f;
@@ -501,19 +528,16 @@ __device__ __forceinline__ void bvh_closest_hit(const BvhArgs &b, const float4 *
     // of min/max per box (half-rate instructions), each t is fma(lo, a, fma(hi, b, c)) with one
     // of a, b zero: the same single rounding, on full-rate instructions only.
     const bool px = ix >= 0.0f, py = iy >= 0.0f, pz = iz >= 0.0f;
-    const float nax = px ? ix : 0.0f, nbx = px ? 0.0f : ix, ncx = px ? nlx : nhx; // entry plane
-    const float fax = px ? 0.0f : ix, fbx = px ? ix : 0.0f, fcx = px ? nhx : nlx; // exit plane
-    const float nay = py ? iy : 0.0f, nby = py ? 0.0f : iy, ncy = py ? nly : nhy;
-    const float fay = py ? 0.0f : iy, fby = py ? iy : 0.0f, fcy = py ? nhy : nly;
-    const float naz = pz ? iz : 0.0f, nbz = pz ? 0.0f : iz, ncz = pz ? nlz : nhz;
-    const float faz = pz ? 0.0f : iz, fbz = pz ? iz : 0.0f, fcz = pz ? nhz : nlz;
+    // entry plane: fma(lo, na, fma(hi, nb, nc)); exit plane: the same with na and nb swapped
+    const float nax = px ? ix : 0.0f, nbx = ix - nax, ncx = px ? nlx : nhx, fcx = px ? nhx : nlx;
+    const float nay = py ? iy : 0.0f, nby = iy - nay, ncy = py ? nly : nhy, fcy = py ? nhy : nly;
+    const float naz = pz ? iz : 0.0f, nbz = iz - naz, ncz = pz ? nlz : nhz, fcz = pz ? nhz : nlz;
+    const float fax = nbx, fbx = nax, fay = nby, fby = nay, faz = nbz, fbz = naz;
     const float t_lo = tmin * (1.0f - 0x1p-20f);
     float t_hi = closest * (1.0f + 0x1p-20f);
 
-    constexpr int kDone = INT_MIN;
-    int node = 0;
-    uint32_t sp = 0u;
-    for (;;) {
+    constexpr int kDone = kBvhDone;
+    while ((uint32_t)__popcll(__ballot(node != kDone)) > suspend) {
         while (node >= 0) {
             const float4 *np = (NODES_IN_LDS ? lds_nodes : b.nodes) + (size_t)node * 4u;
             const float4 l0 = np[0], h0 = np[1], l1 = np[2], h1 = np[3];
@@ -546,7 +570,7 @@ __device__ __forceinline__ void bvh_closest_hit(const BvhArgs &b, const float4 *
             }
         }
         if (node == kDone)
-            break;
+            continue;
         const uint32_t code = (uint32_t)~node, first = code >> 4, count = code & 15u;
         for (uint32_t i0 = 0u; i0 < count; i0 += 4u) {
             // up to four records in flight before the first is used; then every lane walks its
@@ -574,10 +598,12 @@ __device__ __forceinline__ void bvh_closest_hit(const BvhArgs &b, const float4 *
             }
         }
         t_hi = closest * (1.0f + 0x1p-20f);
-        if (sp == 0u)
-            break;
-        --sp;
-        node = (int)stk[sp * kTraceThreads];
+        if (sp == 0u) {
+            node = kDone;
+        } else {
+            --sp;
+            node = (int)stk[sp * kTraceThreads];
+        }
     }
 }
 
@@ -698,6 +724,11 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
     int depth = 0, level = 0;
     uint32_t n_rays = 0u;
     uint32_t n_rounds = 0u; // wave-uniform: passes over the sphere list
+    // hierarchy scan: state of a walk that continues in the next pass
+    int w_node = kBvhDone, w_best = -1;
+    uint32_t w_sp = 0u;
+    float w_closest = INFINITY;
+    bool w_pending = false;
 
     for (;;) {
         // ---- refill idle lanes from the wave's chunk, pulling new chunks as needed
@@ -775,17 +806,33 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
         const bool mine = active && ray.tame; // this lane's ray goes through the matrix filter
         if (FILTER == kFilterMatrix && wave_active)
             matrix_operands(ray, mine, a.shift[0], a.shift[1], a.shift[2], stage + wave * (9 * 64), lane, mo);
+        bool shade = active; // the ray's closest hit is known after this pass
         if (FILTER == kFilterBvh) {
-            if (active) {
+            if (active && !w_pending) { // a ray that starts its scan in this pass
+                w_pending = true;
                 if (ray.tame) {
-                    uint32_t *stk = reinterpret_cast<uint32_t *>(stage) + tid;
-                    if (a.bvh.lds_nodes)
-                        bvh_closest_hit<true>(a.bvh, bvh_lds, ray, stk, 0.001f, closest, best);
-                    else
-                        bvh_closest_hit<false>(a.bvh, nullptr, ray, stk, 0.001f, closest, best);
+                    bvh_begin(a.bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best);
+                } else { // the reference's in-order loop over the whole list, from memory
+                    w_closest = INFINITY;
+                    w_best = -1;
+                    w_node = kBvhDone;
+                    scan_tile<kFilterExact>(a.exact, a.exact, a.n, 0u, ray, 0.001f, w_closest, w_best);
                 }
-                else // the reference's in-order loop over the whole list, from memory
-                    scan_tile<kFilterExact>(a.exact, a.exact, a.n, 0u, ray, 0.001f, closest, best);
+            }
+            if (wave_active) {
+                uint32_t *stk = reinterpret_cast<uint32_t *>(stage) + tid;
+                const bool walking = active && w_node != kBvhDone;
+                if (a.bvh.lds_nodes)
+                    bvh_walk<true>(a.bvh, bvh_lds, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best);
+                else
+                    bvh_walk<false>(a.bvh, nullptr, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best);
+            }
+            if (active && w_node == kBvhDone) {
+                w_pending = false;
+                closest = w_closest;
+                best = w_best;
+            } else {
+                shade = false; // still walking: continues in the next pass
             }
         }
         for (uint32_t t0 = 0u; FILTER != kFilterBvh && t0 < (MULTI_TILE ? a.n : 1u); t0 += a.tile_cap) {
@@ -810,7 +857,7 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
 
         // ---- GetRayColor's branches, Source/main.cpp:562-597
         bool terminated = false;
-        if (active) {
+        if (shade) {
             ++n_rays;
             int cr = 0, cg = 0, cb = 0;
             if (best < 0) {
