@@ -258,7 +258,8 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
         a.tile_cap = 0u; // the walk reads nodes and leaf records from memory
     a.aux_bytes = trace_aux_bytes(a.filter, a.bvh.levels, a.bvh.lds_nodes);
 
-    const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth);
+    a.stack_entry_bytes = a.n <= 65536u ? 2u : 4u;
+    const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
     if (lds > 160u * 1024u)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_depth too large for the LDS bounce stack");
     int per_cu = 0;

@@ -52,6 +52,7 @@ struct TraceArgs {
     int32_t filter;
     float shift[3];            // origin of the matrix filter's coordinates
     uint32_t tile_cap;         // spheres per LDS tile, multiple of kBlock (0: no tiles)
+    uint32_t stack_entry_bytes; // bounce stack entry: 2 while n <= 65536, else 4
     uint32_t aux_bytes;        // LDS between the tiles and the bounce stack: operand staging or traversal stack
     BvhArgs bvh;               // kFilterBvh only
     rt_camera cam;
@@ -97,7 +98,7 @@ struct IntersectArgs {
 // Bytes of LDS between the tiles and the bounce stack for `filter`.
 uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels, uint32_t bvh_lds_nodes);
 // Bytes of dynamic LDS the trace kernel needs.
-size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth);
+size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth, uint32_t stack_entry_bytes);
 
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream);
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream);

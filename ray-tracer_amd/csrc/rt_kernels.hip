@@ -607,6 +607,21 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
     }
 }
 
+// The bounce stack holds list indices: two bytes per entry while the list has at most 65536
+// spheres, else four.
+__device__ __forceinline__ void push_bounce(uint32_t *stack, uint32_t entry_bytes, int at, uint32_t index)
+{
+    if (entry_bytes == 2u)
+        reinterpret_cast<uint16_t *>(stack)[at] = (uint16_t)index;
+    else
+        stack[at] = index;
+}
+
+__device__ __forceinline__ uint32_t read_bounce(const uint32_t *stack, uint32_t entry_bytes, int at)
+{
+    return entry_bytes == 2u ? (uint32_t)reinterpret_cast<const uint16_t *>(stack)[at] : stack[at];
+}
+
 // Hit point and normal, Source/main.cpp:503-514.
 __device__ __forceinline__ void hit_frame(const RayState &r, float t, float cx, float cy, float cz,
                                           float radius, float &px, float &py, float &pz, float &nx,
@@ -681,7 +696,8 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
     float *stage = reinterpret_cast<float *>(tile_e + a.tile_cap);
     uint32_t *stack = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(stage) + a.aux_bytes);
     const int stack_levels = a.max_depth > 0 ? a.max_depth : 1;
-    uint32_t *wave_flags = stack + (size_t)stack_levels * kTraceThreads;
+    uint32_t *wave_flags = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(stack) +
+                                                        (size_t)stack_levels * kTraceThreads * a.stack_entry_bytes);
     uint32_t *acc_base = wave_flags + 4; // 4 waves x 2 chunk slots x 64 pixels x 3 channels
     const Geom *filt_src = FILTER == kFilterExact ? nullptr : a.geom;
 
@@ -903,7 +919,7 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                         ndy = (ratio * uy - f * ny) * keep;
                         ndz = (ratio * uz - f * nz) * keep;
                     }
-                    stack[level * kTraceThreads + tid] = (uint32_t)best;
+                    push_bounce(stack, a.stack_entry_bytes, level * kTraceThreads + tid, (uint32_t)best);
                     ++level;
                     --depth;
                     ray.ox = px; ray.oy = py; ray.oz = pz;
@@ -932,7 +948,7 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                         ndz = ray.dz - (nz * d) * 2.0f;
                         ndx = ndx + (fuzz * rx); ndy = ndy + (fuzz * ry); ndz = ndz + (fuzz * rz);
                     }
-                    stack[level * kTraceThreads + tid] = (uint32_t)best;
+                    push_bounce(stack, a.stack_entry_bytes, level * kTraceThreads + tid, (uint32_t)best);
                     ++level;
                     --depth;
                     ray.ox = px; ray.oy = py; ray.oz = pz;
@@ -949,7 +965,7 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
             if (terminated) {
                 // unwind the recursion: per level, bytes -> float -> bytes (:569-578, :587-591)
                 for (int l = level - 1; l >= 0; --l) {
-                    const rt_sphere *sp = a.spheres + stack[l * kTraceThreads + tid];
+                    const rt_sphere *sp = a.spheres + read_bounce(stack, a.stack_entry_bytes, l * kTraceThreads + tid);
                     if (sp->material == RT_MAT_DIFFUSE) {
                         cr >>= 1; cg >>= 1; cb >>= 1;
                     }
@@ -1120,17 +1136,17 @@ uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels, uint32_t bvh_lds_nodes
     return 4u * 9u * 64u * (uint32_t)sizeof(float);
 }
 
-size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth)
+size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth, uint32_t stack_entry_bytes)
 {
     const size_t levels = max_depth > 0 ? (size_t)max_depth : 1u;
     return (size_t)tile_cap * 2u * sizeof(Geom) + aux_bytes +
-           levels * kTraceThreads * sizeof(uint32_t) + 4u * sizeof(uint32_t) +
+           levels * kTraceThreads * stack_entry_bytes + 4u * sizeof(uint32_t) +
            4u * 2u * 64u * 3u * sizeof(uint32_t);
 }
 
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream)
 {
-    const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth);
+    const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
     const bool multi = a.filter != kFilterBvh && a.n > a.tile_cap;
     const dim3 grid(n_workgroups), block(kTraceThreads);
     const bool glass = (a.flags & RT_FLAG_DIELECTRIC) != 0u;

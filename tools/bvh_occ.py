@@ -19,14 +19,14 @@ for n, grid, spp in ((500, 11, 64), (10000, 50, 16)):
     ctx.set_scene(scenes.random_spheres(n, grid_half=grid))
     ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_BVH)
     p = rtamd.params(W, H, spp, 8, seed=1)
-    for leaf, lds in ((4, 0), (4, 2048), (2, 2048), (8, 2048)):
+    for leaf, lds in ((4, 0), (4, 512), (8, 512)):
         ctx.set_option(rtamd.OPT_BVH_LEAF_SPHERES, leaf)
         ctx.set_option(rtamd.OPT_BVH_LDS_NODES, lds)
         row = []
         for wg in (3, 4, 5, 6, 8):
             ctx.set_option(rtamd.OPT_WORKGROUPS_PER_CU, wg)
             best = 1e9
-            for it in range(3):
+            for it in range(6):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 ctx.accumulate_device(cam, p, d.data_ptr()); torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
