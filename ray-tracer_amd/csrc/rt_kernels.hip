@@ -460,8 +460,9 @@ __device__ __forceinline__ void scan_tile_matrix(const float *__restrict__ filt,
 // q = |oc|^2, and take its acceptance condition from filter_sign: the hit branch
 // is taken only if the line through C + oc along D passes within
 //     dist^2 <= r^2 + u (19.8 q + 5.2 r^2),                       u = 2^-24,
-// of the centre, and the root T it then accepts lies (with the roundings of
-// B, the square root and the division) at a point whose distance from C is below
+// of the centre, and the root T it then accepts lies (with the roundings of A, B,
+// C, the square root and the division: |P - C|^2 <= r^2 + u (41 q + 25 r^2) for
+// P = O + T D) at a point whose distance from C is below
 //     r_eff = sqrt(r^2 (1 + 64u) + 64u q).
 // So the segment [tmin, closest] of the line meets the ball of radius r_eff at the
 // accepted T, hence also every box that contains the sphere's box once it is
@@ -469,11 +470,13 @@ __device__ __forceinline__ void scan_tile_matrix(const float *__restrict__ filt,
 //     pad >= sqrt(rmin^2 (1 + 64u) + 64u qmax) - rmin,   qmax = (|O - center| + radius)^2 >= q.
 // The slab test runs in coordinates relative to the tree's centre; its own
 // roundings move a plane by less than 8u (|O - center| + radius) and scale a t by
-// less than 1 + 4u, which an extra 2^-10 r_eff of padding (r_eff^2 >= 64u qmax, so
-// this exceeds 2^-1 sqrt(u qmax) = 2^11 u sqrt(qmax)), the factor 1.001 on the whole
-// and the 2^-20 relative slack on [tmin, closest] cover.  A direction component too small to divide by is replaced by
-// 2^-50 of the largest one: over any distance inside the tree that moves the ray
-// by less than 2^-49 of the tree's size.  Only tame rays walk the tree.
+// less than 1 + 4u, which an extra 2^-10 r_eff of padding (r_eff >= sqrt(64u qmax),
+// so this is at least 2^-19 sqrt(qmax) = 32u sqrt(qmax)), the factor 1.001 on the
+// whole and the 2^-20 relative slack on [tmin, closest] cover.  A direction component
+// too small to divide by is replaced by 2^-50 of the largest one: over any distance
+// inside the tree that moves the ray by less than 2^-49 of the tree's size.  Only
+// tame rays walk the tree.
+//
 // The walk is resumable.  Its per-ray state is (node, sp, closest, best) plus the ray's stack
 // column in LDS; a wave stops walking when no more than `suspend` of its lanes are still at it
 // (unless that was already so when it started), the finished rays go on to shading, and the

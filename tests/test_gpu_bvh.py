@@ -52,6 +52,13 @@ def test_ten_thousand_spheres(ctx):
     same_as_oracle(ctx, sc, ((0.0, 30.0, 0.0), (5.0, 0.0, 5.0), (0.0, 0.0, 1.0), 60.0), 64, 36, 2, 8, 5)  # from above
 
 
+def test_hundred_thousand_spheres_walked_from_memory(ctx):
+    """A tree far too large for LDS (33 000 nodes, 17 levels): nodes and leaf records come through
+    the caches, and bounce stack entries take four bytes (n > 65536)."""
+    sc = scenes.random_spheres(100000, grid_half=160, seed=5)
+    same_as_oracle(ctx, sc, ((40.0, 6.0, 10.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 30.0), 48, 27, 2, 6, 8)
+
+
 def test_coincident_and_nested_spheres_keep_the_tie_rule(ctx):
     """Equal hit distance: the later sphere of the list wins (Source/main.cpp:492-499, 539-545),
     wherever the hierarchy has put the two."""

@@ -14,7 +14,7 @@ s = torch.cuda.current_stream().cuda_stream
 for depth in (8, 1):
     p = rtamd.params(W, H, 64, depth, seed=1)
     best = 1e9
-    for it in range(4):
+    for it in range(6):
         ctx.reset_stats(); torch.cuda.synchronize(); t0 = time.time()
         ctx.accumulate_device(cam, p, d.data_ptr(), stream=s); torch.cuda.synchronize(); best = min(best, time.time() - t0)
     st = ctx.stats()

@@ -1,0 +1,62 @@
+"""Builds timing-only variants of the library (tools/librt_diagN.so), each with one part of the
+kernel cheapened or doubled, to see what that part costs.  Their images are NOT the reference's;
+they are never shipped or tested.  Usage: python tools/diag_variants.py [N ...]"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ray-tracer_amd", "csrc")
+FLAGS = ("-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt "
+         "-fno-fast-math -fno-slp-vectorize").split()
+
+
+def rep(s, a, b):
+    assert a in s, a[:60]
+    return s.replace(a, b)
+
+
+def variant(n, s):
+    if n == 1:  # a three-multiply hash instead of Philox
+        return rep(s, "    uint32_t c3 = 0u;\n#pragma unroll\n    for (int r = 0; r < 10; ++r) {", """    uint32_t c3 = 0u;
+    {
+        uint32_t h = (c0 * 0x9E3779B1u) ^ (c1 * 0x85EBCA77u) ^ (c2 * 0xC2B2AE3Du) ^ k0;
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+        out[0] = h; out[1] = h * 0x9E3779B1u + 0x7F4A7C15u; out[2] = (h ^ (h >> 7)) * 0x85EBCA77u; out[3] = h + k1;
+        out[1] ^= out[1] >> 13; out[2] ^= out[2] >> 11;
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {""")
+    if n == 3:  # no replay of the bounce stack
+        return rep(s, "for (int l = level - 1; l >= 0; --l) {", "for (int l = level - 1; l >= level; --l) {")
+    if n == 4:  # every ray walks the hierarchy twice
+        return rep(s, "                    bvh_begin(a.bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best);", """                    bvh_begin(a.bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best);
+                    { int n2 = w_node; uint32_t s2 = 0u; float c2 = w_closest; int b2 = w_best; RayState r2 = ray;
+                      uint32_t *stk2 = reinterpret_cast<uint32_t *>(stage) + tid;
+                      BvhArgs bb = a.bvh; bb.suspend_lanes = 0u;
+                      bvh_walk<false>(bb, nullptr, r2, stk2, n2 != kBvhDone, 0.001f, n2, s2, c2, b2);
+                      if (b2 == 12345678) w_closest = c2; }""")
+    if n == 7:  # the first point drawn is always accepted
+        return rep(s, "        if (((x * x) + (y * y) + (z * z)) < 1.0f)\n            return;", "        return;")
+    if n == 8:  # no refill arithmetic: every lane keeps its first pixel (timing only)
+        return rep(s, "                const uint32_t s = item / (uint32_t)ch_npx;\n                const uint32_t p = item - s * (uint32_t)ch_npx;\n                const int ly = (int)(p / (uint32_t)ch_tw);\n                const int lx = (int)p - ly * ch_tw;",
+                   "                const uint32_t s = item >> 6;\n                const uint32_t p = item & 63u;\n                const int ly = (int)(p >> 3);\n                const int lx = (int)(p & 7u);")
+    raise SystemExit(f"no variant {n}")
+
+
+def main():
+    src = open(os.path.join(CSRC, "rt_kernels.hip")).read()
+    os.makedirs("/tmp/diag", exist_ok=True)
+    procs = []
+    for n in [int(x) for x in sys.argv[1:]] or [1, 3, 4, 7, 8]:
+        path = f"/tmp/diag/rt_kernels_d{n}.hip"
+        open(path, "w").write(variant(n, src))
+        out = os.path.join(ROOT, "tools", f"librt_diag{n}.so")
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", *FLAGS, f"-I{ROOT}/include", f"-I{CSRC}", "-shared", "-o", out,
+                                       path, "-x", "hip", os.path.join(CSRC, "rt_capi.cpp"), os.path.join(CSRC, "rt_bvh.cpp")]))
+    sys.exit(max(p.wait() for p in procs))
+
+
+if __name__ == "__main__":
+    main()
