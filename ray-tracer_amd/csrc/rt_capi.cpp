@@ -185,6 +185,43 @@ int ensure_bvh(rt_context *ctx)
     return RT_OK;
 }
 
+// The scan the current options select for this scene.
+int chosen_filter(const rt_context *ctx)
+{
+    int f = ctx->scene_tame ? ctx->filter : (int)kFilterExact;
+    if (f == kFilterMatrix && !ctx->filter_forced) {
+        // the matrix scan works on groups of 128 spheres; a handful of spheres is cheaper on the
+        // vector ALU, and from a few dozen up a walk over boxes beats both (measured crossover)
+        if (ctx->n_spheres < 96u)
+            f = kFilterConservative;
+        if (ctx->n_spheres >= ctx->bvh_auto_min)
+            f = kFilterBvh;
+    }
+    return f;
+}
+
+// Builds the hierarchy if need be and fills the kernels' view of it.
+int bvh_args(rt_context *ctx, BvhArgs &out)
+{
+    const int st = ensure_bvh(ctx);
+    if (st != RT_OK)
+        return st;
+    const BvhHost &b = ctx->bvh;
+    out.nodes = ctx->d_bvh_nodes;
+    out.leaf_geom = ctx->d_bvh_geom;
+    out.leaf_index = ctx->d_bvh_index;
+    out.n_nodes = (uint32_t)b.nodes.size();
+    out.n_large = b.n_large;
+    out.levels = b.levels ? b.levels : 1u;
+    out.lds_nodes = out.n_nodes <= ctx->bvh_lds_nodes_max ? out.n_nodes : 0u;
+    out.suspend_lanes = ctx->bvh_suspend_lanes;
+    memcpy(out.center, b.center, sizeof out.center);
+    out.radius2 = std::nextafter(b.radius * b.radius, INFINITY);
+    out.rmin = b.rmin;
+    out.rmin2w = b.rmin2w;
+    return RT_OK;
+}
+
 // Enqueues the sample loop for `region` into d_sums.
 int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p, const Region &rg,
                        uint32_t *d_sums, hipStream_t stream)
@@ -196,29 +233,11 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
 
     TraceArgs a;
     memset(&a, 0, sizeof a);
-    a.filter = ctx->scene_tame ? ctx->filter : (int)kFilterExact;
-    // the matrix scan works on groups of 128 spheres; a handful of spheres is cheaper on the vector ALU
-    if (a.filter == kFilterMatrix && !ctx->filter_forced && ctx->n_spheres < 96u)
-        a.filter = kFilterConservative;
-    if (a.filter == kFilterMatrix && !ctx->filter_forced && ctx->n_spheres >= ctx->bvh_auto_min)
-        a.filter = kFilterBvh;
+    a.filter = chosen_filter(ctx);
     if (a.filter == kFilterBvh) {
-        const int st = ensure_bvh(ctx);
+        const int st = bvh_args(ctx, a.bvh);
         if (st != RT_OK)
             return st;
-        const BvhHost &b = ctx->bvh;
-        a.bvh.nodes = ctx->d_bvh_nodes;
-        a.bvh.leaf_geom = ctx->d_bvh_geom;
-        a.bvh.leaf_index = ctx->d_bvh_index;
-        a.bvh.n_nodes = (uint32_t)b.nodes.size();
-        a.bvh.n_large = b.n_large;
-        a.bvh.levels = b.levels ? b.levels : 1u;
-        a.bvh.lds_nodes = a.bvh.n_nodes <= ctx->bvh_lds_nodes_max ? a.bvh.n_nodes : 0u;
-        a.bvh.suspend_lanes = ctx->bvh_suspend_lanes;
-        memcpy(a.bvh.center, b.center, sizeof a.bvh.center);
-        a.bvh.radius2 = std::nextafter(b.radius * b.radius, INFINITY);
-        a.bvh.rmin = b.rmin;
-        a.bvh.rmin2w = b.rmin2w;
     }
     a.geom = a.filter == kFilterMatrix ? ctx->d_geom_matrix : ctx->d_geom_filter;
     a.exact = ctx->d_geom_exact;
@@ -653,6 +672,14 @@ int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width
         return fail(ctx, RT_ERR_NO_SCENE, "rt_set_scene has not been called");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     HitsArgs a;
+    memset(&a, 0, sizeof a);
+    if (chosen_filter(ctx) == kFilterBvh) {
+        const int st = bvh_args(ctx, a.bvh);
+        if (st != RT_OK)
+            return st;
+        a.bvh.suspend_lanes = 0u; // one ray per lane, nothing to go on to
+        a.use_bvh = 1u;
+    }
     a.geom = (ctx->scene_tame && ctx->filter != kFilterExact) ? ctx->d_geom_filter : nullptr;
     a.exact = ctx->d_geom_exact;
     a.n = ctx->n_spheres; a.cam = *cam;
@@ -710,17 +737,24 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out)
     hipError_t e = hipMemcpyAsync(d_rays, rays, in_bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         IntersectArgs a;
+        memset(&a, 0, sizeof a);
+        if (chosen_filter(ctx) == kFilterBvh) {
+            st = bvh_args(ctx, a.bvh);
+            a.bvh.suspend_lanes = 0u;
+            a.use_bvh = 1u;
+        }
         a.geom = (ctx->scene_tame && ctx->filter != kFilterExact) ? ctx->d_geom_filter : nullptr;
         a.exact = ctx->d_geom_exact;
         a.spheres = ctx->d_spheres; a.n = ctx->n_spheres;
         a.rays = d_rays; a.n_rays = n; a.out = d_out;
-        e = launch_intersect(a, ctx->stream);
+        if (st == RT_OK)
+            e = launch_intersect(a, ctx->stream);
     }
-    if (e == hipSuccess)
+    if (e == hipSuccess && st == RT_OK)
         e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess)
+    if (e != hipSuccess && st == RT_OK)
         st = fail_hip(ctx, e, "rt_intersect");
     (void)hipFree(d_rays);
     (void)hipFree(d_out);

@@ -83,6 +83,8 @@ struct HitsArgs {
     rt_camera cam;
     uint32_t width, height;
     int32_t *hits;
+    uint32_t use_bvh;          // walk `bvh` instead of scanning the list
+    BvhArgs bvh;
 };
 
 struct IntersectArgs {
@@ -93,6 +95,8 @@ struct IntersectArgs {
     const float *rays;
     uint32_t n_rays;
     uint8_t *out; // 32 bytes per ray
+    uint32_t use_bvh;          // walk `bvh` instead of scanning the list
+    BvhArgs bvh;
 };
 
 // Bytes of LDS between the tiles and the bounce stack for `filter`.

@@ -610,6 +610,23 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
     }
 }
 
+// One whole walk for the one-ray-per-lane kernels (all 64 lanes call; `have` = this lane holds a
+// ray).  Rays outside the walk's preconditions take the reference's in-order loop from memory.
+__device__ __forceinline__ void closest_hit_by_hierarchy(const BvhArgs &b, const Geom *exact, uint32_t n,
+                                                         const RayState &r, bool have, uint32_t *stk,
+                                                         float &closest, int &best)
+{
+    int node = kBvhDone;
+    uint32_t sp = 0u;
+    if (have) {
+        if (r.tame)
+            bvh_begin(b, r, 0.001f, node, sp, closest, best);
+        else
+            scan_tile<kFilterExact>(exact, exact, n, 0u, r, 0.001f, closest, best);
+    }
+    bvh_walk<false>(b, nullptr, r, stk, have && node != kBvhDone, 0.001f, node, sp, closest, best);
+}
+
 // The bounce stack holds list indices: two bytes per entry while the list has at most 65536
 // spheres, else four.
 __device__ __forceinline__ void push_bounce(uint32_t *stack, uint32_t entry_bytes, int at, uint32_t index)
@@ -1059,7 +1076,10 @@ __global__ void __launch_bounds__(256) primary_hits_kernel(const HitsArgs a, uin
 
     float closest = INFINITY;
     int best = -1;
-    for (uint32_t t0 = 0u; t0 < a.n; t0 += tile_cap) {
+    if (a.use_bvh) // smem is the walk's stack
+        closest_hit_by_hierarchy(a.bvh, a.exact, a.n, ray, inside, reinterpret_cast<uint32_t *>(smem) + threadIdx.x,
+                                 closest, best);
+    for (uint32_t t0 = 0u; !a.use_bvh && t0 < a.n; t0 += tile_cap) {
         const uint32_t cnt = min(tile_cap, a.n - t0);
         __syncthreads();
         load_tile(tile_f, tile_e, a.geom, a.exact, t0, round_up_group(cnt));
@@ -1093,7 +1113,10 @@ __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, u
     }
     float closest = INFINITY;
     int best = -1;
-    for (uint32_t t0 = 0u; t0 < a.n; t0 += tile_cap) {
+    if (a.use_bvh)
+        closest_hit_by_hierarchy(a.bvh, a.exact, a.n, ray, inside, reinterpret_cast<uint32_t *>(smem) + threadIdx.x,
+                                 closest, best);
+    for (uint32_t t0 = 0u; !a.use_bvh && t0 < a.n; t0 += tile_cap) {
         const uint32_t cnt = min(tile_cap, a.n - t0);
         __syncthreads();
         load_tile(tile_f, tile_e, a.geom, a.exact, t0, round_up_group(cnt));
@@ -1215,8 +1238,8 @@ hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream)
         return hipSuccess;
     const uint32_t cap = scan_tile_cap(a.n);
     dim3 grid((a.width + 63u) / 64u, (a.height + 3u) / 4u);
-    hipLaunchKernelGGL(primary_hits_kernel, grid, dim3(256), (size_t)cap * 2u * sizeof(Geom), stream,
-                       a, cap);
+    const size_t lds = a.use_bvh ? (size_t)a.bvh.levels * 256u * sizeof(uint32_t) : (size_t)cap * 2u * sizeof(Geom);
+    hipLaunchKernelGGL(primary_hits_kernel, grid, dim3(256), lds, stream, a, cap);
     return hipGetLastError();
 }
 
@@ -1225,8 +1248,8 @@ hipError_t launch_intersect(const IntersectArgs &a, hipStream_t stream)
     if (a.n_rays == 0u)
         return hipSuccess;
     const uint32_t cap = scan_tile_cap(a.n);
-    hipLaunchKernelGGL(intersect_kernel, dim3((a.n_rays + 255u) / 256u), dim3(256),
-                       (size_t)cap * 2u * sizeof(Geom), stream, a, cap);
+    const size_t lds = a.use_bvh ? (size_t)a.bvh.levels * 256u * sizeof(uint32_t) : (size_t)cap * 2u * sizeof(Geom);
+    hipLaunchKernelGGL(intersect_kernel, dim3((a.n_rays + 255u) / 256u), dim3(256), lds, stream, a, cap);
     return hipGetLastError();
 }
 

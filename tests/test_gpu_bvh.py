@@ -56,7 +56,11 @@ def test_hundred_thousand_spheres_walked_from_memory(ctx):
     """A tree far too large for LDS (33 000 nodes, 17 levels): nodes and leaf records come through
     the caches, and bounce stack entries take four bytes (n > 65536)."""
     sc = scenes.random_spheres(100000, grid_half=160, seed=5)
-    same_as_oracle(ctx, sc, ((40.0, 6.0, 10.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 30.0), 48, 27, 2, 6, 8)
+    cam = ((40.0, 6.0, 10.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 30.0)
+    same_as_oracle(ctx, sc, cam, 48, 27, 2, 6, 8)
+    hits = ctx.primary_hits(rtamd.make_camera(*cam), 128, 72)
+    assert np.array_equal(hits, O.primary_hits(sc, O.camera(*cam), 128, 72))
+    assert len(np.unique(hits)) > 50
 
 
 def test_coincident_and_nested_spheres_keep_the_tie_rule(ctx):

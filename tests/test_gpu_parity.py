@@ -55,7 +55,7 @@ def test_primary_hits_default_scene_matches_reference_map(ctx):
     assert "%016x" % O.fnv1a64(got) == KAT["c2_default_fnv"]
 
 
-@pytest.mark.parametrize("filt", [rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE])
+@pytest.mark.parametrize("filt", [rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_BVH])
 def test_primary_hits_random_spheres_matches_reference_map(ctx, filt):
     ctx.set_option(rtamd.OPT_FILTER, filt)
     ctx.set_scene(c3_scene())
@@ -69,15 +69,21 @@ def test_generated_scene_equals_committed_fixture():
     assert scenes.random_spheres(500).tobytes() == c3_scene().tobytes()
 
 
+@pytest.mark.parametrize("filt", [rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_BVH])
 @pytest.mark.parametrize("name", ["default", "c3scene"])
-def test_intersect_matches_reference_vectors(ctx, name):
+def test_intersect_matches_reference_vectors(ctx, name, filt):
     z = np.load(os.path.join(G, f"isect_{name}.npz"))
     ctx.set_scene(rtamd.default_scene() if name == "default" else c3_scene())
-    got = ctx.intersect(z["rays"])
+    ctx.set_option(rtamd.OPT_FILTER, filt)
+    try:
+        got = ctx.intersect(z["rays"])
+    finally:
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
     assert got.tobytes() == z["out"].tobytes()
 
 
-def test_intersect_ties_inside_tangent_and_degenerate(ctx):
+@pytest.mark.parametrize("filt", [rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_BVH])
+def test_intersect_ties_inside_tangent_and_degenerate(ctx, filt):
     """Later sphere wins equal T; origins inside spheres; zero-length and NaN directions."""
     rs = np.random.RandomState(11)
     n = 70  # not a multiple of 32: ragged last mask word
@@ -98,7 +104,14 @@ def test_intersect_ties_inside_tangent_and_degenerate(ctx):
     rays[130, :3] = (np.inf, 0.0, 0.0)
     rays[131, 3:] = (1e30, 1e30, 1e30)
     rays[132, 3:] = (1e-30, 0.0, 0.0)
-    got = ctx.intersect(rays)
+    rays[133:160, 3] = 0.0  # axis-parallel directions: zero components
+    rays[160:180, 3:5] = 0.0
+    rays[180:190, 4] = 1e-35
+    ctx.set_option(rtamd.OPT_FILTER, filt)
+    try:
+        got = ctx.intersect(rays)
+    finally:
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
     t, p, nrm = C.c_float(), (C.c_float * 3)(), (C.c_float * 3)()
     ties = 0
     for i, r in enumerate(rays):
