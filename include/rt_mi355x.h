@@ -93,7 +93,12 @@ enum {
      * on the normalised direction, colour = Color * child colour like Metal. */
     RT_FLAG_DIELECTRIC = 1u,
     /* rt_resolve / rt_render apply gamma 2: byte = trunc(sqrt((sum / spp) / 255) * 255). */
-    RT_FLAG_GAMMA2 = 2u
+    RT_FLAG_GAMMA2 = 2u,
+    /* The reference truncates the colour to bytes at every recursion level (ToRGB inside
+     * GetRayColor, Source/main.cpp:569-578, 587-591).  With this flag it stays in float between
+     * the levels (Diffuse halves by * 0.5f), still limited to [0, 255] per level, and each sample
+     * is truncated to bytes once. */
+    RT_FLAG_FLOAT_SHADING = 4u
 };
 
 typedef struct rt_stats {

@@ -341,6 +341,64 @@ static void point_in_unit_sphere(rng_t *rng, float p[3])
     }
 }
 
+/* The scattering half of GetRayColor's material branches, Source/main.cpp:563-594: fills the
+ * child ray's direction R and returns how the child's colour enters the parent's:
+ * 0 no child (flat white), 1 Color * (child / 2) (Diffuse), 2 Color * child. */
+static int scatter(const orc_sphere *s, const hit_t *rec, const float D[3], rng_t *rng, float R[3])
+{
+    if (s->material == ORC_MAT_DIFFUSE) {
+        float r[3];
+        point_in_unit_sphere(rng, r);
+        for (int i = 0; i < 3; i++)
+            R[i] = rec->normal[i] + r[i];
+        return 1;
+    }
+    if (s->material == ORC_MAT_METAL) {
+        /* glm::reflect: I - N * dot(N, I) * 2, func_geometric.inl:110-116 */
+        float d = dot3(rec->normal, D);
+        float r[3];
+        for (int i = 0; i < 3; i++)
+            R[i] = D[i] - (rec->normal[i] * d) * 2.0f;
+        point_in_unit_sphere(rng, r);
+        for (int i = 0; i < 3; i++)
+            R[i] = R[i] + (s->fuzz * r[i]);
+        return 2;
+    }
+    if (s->material == ORC_MAT_GLASS && (rng->flags & ORC_FLAG_DIELECTRIC)) {
+        /* EXTENSION (not in the reference, whose Glass is flat white, :594): a dielectric of
+         * index 1.5 in the style of the book the reference follows.  One RandomFloat() draw
+         * decides between reflection and refraction; glm::reflect / glm::refract
+         * (func_geometric.inl:110-127) act on the normalised direction; every float operation
+         * is written out so that the GPU kernel can repeat it bit for bit. */
+        float inv = 1.0f / sqrtf(dot3(D, D));
+        float U[3] = { D[0] * inv, D[1] * inv, D[2] * inv };
+        float ratio = rec->inside ? 1.5f : (1.0f / 1.5f);
+        float nu = dot3(rec->normal, U); /* dot(N, I) <= 0: N opposes the ray */
+        float cos_theta = -nu;
+        if (cos_theta > 1.0f) cos_theta = 1.0f;
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        float r0 = (1.0f - ratio) / (1.0f + ratio);
+        r0 = r0 * r0;
+        float m = 1.0f - cos_theta;
+        float m5 = ((m * m) * (m * m)) * m;
+        float reflectance = r0 + (1.0f - r0) * m5;
+        uint32_t w[1];
+        rng_words(rng, 1, w);
+        if (ratio * sin_theta > 1.0f || reflectance > orc_u32_to_unit_float(w[0])) {
+            for (int i = 0; i < 3; i++)
+                R[i] = U[i] - (rec->normal[i] * nu) * 2.0f;
+        } else {
+            float k = 1.0f - (ratio * ratio) * (1.0f - nu * nu);
+            float f = ratio * nu + sqrtf(k);
+            float keep = k >= 0.0f ? 1.0f : 0.0f;
+            for (int i = 0; i < 3; i++)
+                R[i] = (ratio * U[i] - f * rec->normal[i]) * keep;
+        }
+        return 2;
+    }
+    return 0; /* :594 */
+}
+
 /* GetRayColor, Source/main.cpp:551-598. */
 static void ray_color(const orc_sphere *spheres, uint32_t n, const float O[3], const float D[3],
                       int depth, rng_t *rng, uint64_t *rays, uint8_t out[3])
@@ -359,72 +417,60 @@ static void ray_color(const orc_sphere *spheres, uint32_t n, const float O[3], c
     }
 
     const orc_sphere *s = &spheres[idx];
-    if (s->material == ORC_MAT_DIFFUSE) {
-        float r[3], S[3];
-        point_in_unit_sphere(rng, r);
-        for (int i = 0; i < 3; i++)
-            S[i] = rec.normal[i] + r[i];
-        uint8_t c[3];
-        ray_color(spheres, n, rec.point, S, depth - 1, rng, rays, c);
-        for (int i = 0; i < 3; i++) {
-            uint8_t h = (uint8_t)(c[i] / 2);
-            out[i] = orc_to_byte(s->color[i] * (float)h);
-        }
+    float R[3];
+    const int kind = scatter(s, &rec, D, rng, R);
+    if (kind == 0) {
+        out[0] = out[1] = out[2] = 255; /* :594 */
         return;
     }
-    if (s->material == ORC_MAT_METAL) {
-        /* glm::reflect: I - N * dot(N, I) * 2, func_geometric.inl:110-116 */
-        float d = dot3(rec.normal, D);
-        float R[3], r[3];
-        for (int i = 0; i < 3; i++)
-            R[i] = D[i] - (rec.normal[i] * d) * 2.0f;
-        point_in_unit_sphere(rng, r);
-        for (int i = 0; i < 3; i++)
-            R[i] = R[i] + (s->fuzz * r[i]);
-        uint8_t c[3];
-        ray_color(spheres, n, rec.point, R, depth - 1, rng, rays, c);
-        for (int i = 0; i < 3; i++)
-            out[i] = orc_to_byte(s->color[i] * (float)c[i]);
+    uint8_t c[3];
+    ray_color(spheres, n, rec.point, R, depth - 1, rng, rays, c);
+    for (int i = 0; i < 3; i++) {
+        uint8_t h = kind == 1 ? (uint8_t)(c[i] / 2) : c[i]; /* :569-571 */
+        out[i] = orc_to_byte(s->color[i] * (float)h);       /* :573-578, :587-591 */
+    }
+}
+
+/* EXTENSION (ORC_FLAG_FLOAT_SHADING): the same recursion with the colour kept in float between
+ * the levels -- no truncation to bytes, Diffuse halves by * 0.5f -- but still limited to
+ * [0, 255] at every level like ToRGB does (the reference's diffuse colours are on a 0..255
+ * scale and rely on that limit); NaN counts as 0.  The sample is truncated to bytes once. */
+static float limit_255(float v)
+{
+    return v > 0.0f ? (v < 255.0f ? v : 255.0f) : 0.0f; /* false for NaN: 0 */
+}
+
+static void ray_color_float(const orc_sphere *spheres, uint32_t n, const float O[3], const float D[3],
+                            int depth, rng_t *rng, uint64_t *rays, float out[3])
+{
+    if (depth <= 0) {
+        out[0] = out[1] = out[2] = 0.0f;
         return;
     }
-    if (s->material == ORC_MAT_GLASS && (rng->flags & ORC_FLAG_DIELECTRIC)) {
-        /* EXTENSION (not in the reference, whose Glass is flat white, :594): a dielectric of
-         * index 1.5 in the style of the book the reference follows.  One RandomFloat() draw
-         * decides between reflection and refraction; glm::reflect / glm::refract
-         * (func_geometric.inl:110-127) act on the normalised direction; every float operation
-         * is written out so that the GPU kernel can repeat it bit for bit. */
-        float inv = 1.0f / sqrtf(dot3(D, D));
-        float U[3] = { D[0] * inv, D[1] * inv, D[2] * inv };
-        float ratio = rec.inside ? 1.5f : (1.0f / 1.5f);
-        float nu = dot3(rec.normal, U); /* dot(N, I) <= 0: N opposes the ray */
-        float cos_theta = -nu;
-        if (cos_theta > 1.0f) cos_theta = 1.0f;
-        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-        float r0 = (1.0f - ratio) / (1.0f + ratio);
-        r0 = r0 * r0;
-        float m = 1.0f - cos_theta;
-        float m5 = ((m * m) * (m * m)) * m;
-        float reflectance = r0 + (1.0f - r0) * m5;
-        uint32_t w[1];
-        rng_words(rng, 1, w);
-        float R[3];
-        if (ratio * sin_theta > 1.0f || reflectance > orc_u32_to_unit_float(w[0])) {
-            for (int i = 0; i < 3; i++)
-                R[i] = U[i] - (rec.normal[i] * nu) * 2.0f;
-        } else {
-            float k = 1.0f - (ratio * ratio) * (1.0f - nu * nu);
-            float f = ratio * nu + sqrtf(k);
-            float keep = k >= 0.0f ? 1.0f : 0.0f;
-            for (int i = 0; i < 3; i++)
-                R[i] = (ratio * U[i] - f * rec.normal[i]) * keep;
-        }
-        uint8_t c[3];
-        ray_color(spheres, n, rec.point, R, depth - 1, rng, rays, c);
+    hit_t rec;
+    (*rays)++;
+    int32_t idx = intersect_scene(spheres, n, O, D, 0.001f, INFINITY, &rec);
+    if (idx < 0) { /* GetGradientColorAtRay, :461-467, before its conversion to integers */
+        static const float v1[3] = { 255.0f, 255.0f, 255.0f };
+        static const float v2[3] = { 128.0f, 178.0f, 255.0f };
+        float t = D[1] * 1.8f;
         for (int i = 0; i < 3; i++)
-            out[i] = orc_to_byte(s->color[i] * (float)c[i]);
+            out[i] = limit_255((1.0f - t) * v1[i] + t * v2[i]);
         return;
     }
-    out[0] = out[1] = out[2] = 255; /* :594 */
+    const orc_sphere *s = &spheres[idx];
+    float R[3];
+    const int kind = scatter(s, &rec, D, rng, R);
+    if (kind == 0) {
+        out[0] = out[1] = out[2] = 255.0f;
+        return;
+    }
+    float c[3];
+    ray_color_float(spheres, n, rec.point, R, depth - 1, rng, rays, c);
+    for (int i = 0; i < 3; i++) {
+        float h = kind == 1 ? c[i] * 0.5f : c[i];
+        out[i] = limit_255(s->color[i] * h);
+    }
 }
 
 /* One sample: Source/main.cpp:627-631. */
@@ -440,7 +486,14 @@ static void sample_color(const orc_sphere *spheres, uint32_t n, const orc_camera
     float v = (float)(((double)(float)j + rv) / (double)(float)height);
     float O[3], D[3];
     orc_get_ray(cam, u, v, O, D);
-    ray_color(spheres, n, O, D, max_depth, rng, rays, out);
+    if (rng->flags & ORC_FLAG_FLOAT_SHADING) {
+        float f[3];
+        ray_color_float(spheres, n, O, D, max_depth, rng, rays, f);
+        for (int k = 0; k < 3; k++)
+            out[k] = orc_to_byte(f[k]);
+    } else {
+        ray_color(spheres, n, O, D, max_depth, rng, rays, out);
+    }
 }
 
 void orc_sample_color(const orc_sphere *spheres, uint32_t n, const orc_camera *cam,

@@ -102,8 +102,9 @@ void orc_trace_tile(const orc_sphere *spheres, uint32_t n, const orc_camera *cam
                     uint64_t *rays);
 
 /* Extensions the reference does not have (default off everywhere): a real dielectric for
- * Material::Glass, and gamma 2 on output.  Parity for them is CPU oracle <-> GPU only. */
-enum { ORC_FLAG_DIELECTRIC = 1u, ORC_FLAG_GAMMA2 = 2u };
+ * Material::Glass, gamma 2 on output, and colour kept in float between the recursion levels.
+ * Parity for them is CPU oracle <-> GPU only. */
+enum { ORC_FLAG_DIELECTRIC = 1u, ORC_FLAG_GAMMA2 = 2u, ORC_FLAG_FLOAT_SHADING = 4u };
 void orc_trace_tile_ext(const orc_sphere *spheres, uint32_t n, const orc_camera *cam,
                         uint32_t width, uint32_t height, uint32_t s0, uint32_t s1, uint32_t spp_div,
                         int32_t max_depth, int rng_mode, uint64_t seed, orc_mt *mt, int xstart,

@@ -122,7 +122,7 @@ int check_params(rt_context *ctx, const rt_camera *cam, const rt_params *p)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "sample range exceeds spp");
     if (!p->sample_count && p->sample_begin != 0)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "sample_begin without sample_count");
-    if ((p->flags & ~(uint32_t)(RT_FLAG_DIELECTRIC | RT_FLAG_GAMMA2)) != 0u || p->reserved != 0u)
+    if ((p->flags & ~(uint32_t)(RT_FLAG_DIELECTRIC | RT_FLAG_GAMMA2 | RT_FLAG_FLOAT_SHADING)) != 0u || p->reserved != 0u)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown flags");
     return RT_OK;
 }

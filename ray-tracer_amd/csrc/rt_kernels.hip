@@ -101,6 +101,21 @@ __device__ __forceinline__ void sky(float dy, int &r, int &g, int &b)
     b = to_byte(omt * 255.0f + t * 255.0f);
 }
 
+// EXTENSION (RT_FLAG_FLOAT_SHADING): colour limited to ToRGB's range but not truncated; NaN -> 0.
+__device__ __forceinline__ float limit_255(float v)
+{
+    return v > 0.0f ? (v < 255.0f ? v : 255.0f) : 0.0f;
+}
+
+__device__ __forceinline__ void sky_float(float dy, float &r, float &g, float &b)
+{
+    const float t = dy * 1.8f;
+    const float omt = 1.0f - t;
+    r = limit_255(omt * 255.0f + t * 128.0f);
+    g = limit_255(omt * 255.0f + t * 178.0f);
+    b = limit_255(omt * 255.0f + t * 255.0f);
+}
+
 // ---------------------------------------------------------------------------
 // Rays
 // ---------------------------------------------------------------------------
@@ -705,7 +720,7 @@ __device__ __forceinline__ uint32_t round_up_group(uint32_t n)
 // (Source/main.cpp:551-598, 613-645), iterative.
 // ---------------------------------------------------------------------------
 
-template <bool MULTI_TILE, int FILTER, bool DIELECTRIC>
+template <bool MULTI_TILE, int FILTER, bool EXT>
 __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -896,13 +911,17 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
         if (shade) {
             ++n_rays;
             int cr = 0, cg = 0, cb = 0;
+            const bool float_shading = EXT && (a.flags & RT_FLAG_FLOAT_SHADING) != 0u;
+            float fr = 0.0f, fg = 0.0f, fb = 0.0f; // terminal colour of the float-shading extension
             if (best < 0) {
                 sky(ray.dy, cr, cg, cb);
+                if (float_shading)
+                    sky_float(ray.dy, fr, fg, fb);
                 terminated = true;
             } else {
                 const rt_sphere *sp = a.spheres + best;
                 const int material = sp->material;
-                const bool dielectric = DIELECTRIC && material == RT_MAT_GLASS;
+                const bool dielectric = EXT && (a.flags & RT_FLAG_DIELECTRIC) != 0u && material == RT_MAT_GLASS;
                 if (dielectric) {
                     // EXTENSION (RT_FLAG_DIELECTRIC; the reference's Glass is flat white, :594):
                     // index 1.5, Schlick reflectance against one RandomFloat() draw, glm::reflect /
@@ -979,10 +998,27 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                     }
                 } else {
                     cr = cg = cb = 255; // :594
+                    fr = fg = fb = 255.0f;
                     terminated = true;
                 }
             }
-            if (terminated) {
+            if (terminated && float_shading) {
+                // EXTENSION (RT_FLAG_FLOAT_SHADING): the same replay with the colour kept in float,
+                // limited to [0, 255] per level, truncated to bytes once per sample
+                for (int l = level - 1; l >= 0; --l) {
+                    const rt_sphere *sp = a.spheres + read_bounce(stack, a.stack_entry_bytes, l * kTraceThreads + tid);
+                    if (sp->material == RT_MAT_DIFFUSE) {
+                        fr = fr * 0.5f; fg = fg * 0.5f; fb = fb * 0.5f;
+                    }
+                    fr = limit_255(sp->color[0] * fr);
+                    fg = limit_255(sp->color[1] * fg);
+                    fb = limit_255(sp->color[2] * fb);
+                }
+                atomicAdd(acc + acc_at + 0u, (uint32_t)to_byte(fr));
+                atomicAdd(acc + acc_at + 1u, (uint32_t)to_byte(fg));
+                atomicAdd(acc + acc_at + 2u, (uint32_t)to_byte(fb));
+                active = false;
+            } else if (terminated) {
                 // unwind the recursion: per level, bytes -> float -> bytes (:569-578, :587-591)
                 for (int l = level - 1; l >= 0; --l) {
                     const rt_sphere *sp = a.spheres + read_bounce(stack, a.stack_entry_bytes, l * kTraceThreads + tid);
@@ -1175,7 +1211,7 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
     const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
     const bool multi = a.filter != kFilterBvh && a.n > a.tile_cap;
     const dim3 grid(n_workgroups), block(kTraceThreads);
-    const bool glass = (a.flags & RT_FLAG_DIELECTRIC) != 0u;
+    const bool glass = (a.flags & (RT_FLAG_DIELECTRIC | RT_FLAG_FLOAT_SHADING)) != 0u; // the extended kernels
 #define RT_LAUNCH_TRACE(F)                                                                        \
     do {                                                                                          \
         if (multi && glass)                                                                       \

@@ -5,7 +5,7 @@
 //   rt_render_cli [--width W --height H --spp N --depth D --seed S]
 //                 [--scene spheres.bin] [--camera fx fy fz ax ay az ux uy uz fov]
 //                 [--out image.ppm] [--progressive SAMPLES_PER_PASS]
-//                 [--dielectric] [--gamma2]      (extensions, off by default)
+//                 [--dielectric] [--gamma2] [--float-shading]   (extensions, off by default)
 // Defaults are the reference's shipped constants: 1024x576, 100 spp, depth 10,
 // its four spheres and its camera.
 #include "RayTracerHost.h"
@@ -52,6 +52,7 @@ int main(int argc, char **argv)
             else if (a == "--progressive") { need(1); per_pass = (unsigned)std::atoi(argv[++i]); }
             else if (a == "--dielectric") state.Flags |= RT_FLAG_DIELECTRIC;
             else if (a == "--gamma2") state.Flags |= RT_FLAG_GAMMA2;
+            else if (a == "--float-shading") state.Flags |= RT_FLAG_FLOAT_SHADING;
             else if (a == "--scene") {
                 need(1);
                 std::ifstream f(argv[++i], std::ios::binary | std::ios::ate);

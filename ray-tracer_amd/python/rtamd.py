@@ -139,7 +139,7 @@ def default_scene():
     return s
 
 
-FLAG_DIELECTRIC, FLAG_GAMMA2 = 1, 2
+FLAG_DIELECTRIC, FLAG_GAMMA2, FLAG_FLOAT_SHADING = 1, 2, 4
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)
 
 

@@ -125,7 +125,7 @@ def new_mt(seed=5489):
     return g
 
 
-FLAG_DIELECTRIC, FLAG_GAMMA2 = 1, 2
+FLAG_DIELECTRIC, FLAG_GAMMA2, FLAG_FLOAT_SHADING = 1, 2, 4
 
 
 def trace_tile(spheres, cam, width, height, spp, depth, rng_mode, seed=0, mt=None, tile=None,

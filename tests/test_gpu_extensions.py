@@ -33,7 +33,8 @@ def glass_default_scene():
     return sc
 
 
-@pytest.mark.parametrize("flags", [rtamd.FLAG_DIELECTRIC, rtamd.FLAG_GAMMA2, rtamd.FLAG_DIELECTRIC | rtamd.FLAG_GAMMA2])
+@pytest.mark.parametrize("flags", [rtamd.FLAG_DIELECTRIC, rtamd.FLAG_GAMMA2, rtamd.FLAG_DIELECTRIC | rtamd.FLAG_GAMMA2,
+                                   rtamd.FLAG_FLOAT_SHADING, rtamd.FLAG_FLOAT_SHADING | rtamd.FLAG_DIELECTRIC | rtamd.FLAG_GAMMA2])
 @pytest.mark.parametrize("scene", ["glass_default", "c3"])
 def test_flagged_frames_bit_exact_against_oracle(ctx, scene, flags):
     sc, cam, W, H, spp, depth = (
@@ -68,7 +69,7 @@ def test_dielectric_same_bits_under_every_scan(ctx):
 def test_unknown_flags_are_rejected(ctx):
     ctx.set_scene(rtamd.default_scene())
     with pytest.raises(rtamd.RtError):
-        ctx.render(rtamd.default_camera(), rtamd.params(16, 16, 1, 2, flags=4))
+        ctx.render(rtamd.default_camera(), rtamd.params(16, 16, 1, 2, flags=8))
     p = rtamd.params(16, 16, 1, 2)
     p.reserved = 1
     with pytest.raises(rtamd.RtError):
