@@ -19,7 +19,7 @@ namespace {
 constexpr int kBins = 16;
 constexpr int kSahDepth = 28;    // below this depth: even splits only
 constexpr uint32_t kMaxLarge = 16;
-constexpr double kLargeRatio = 8.0; // "large" = radius above 8 x the median radius
+constexpr double kLargeRatio = 4.0; // "large" = radius above 4 x the median radius (measured: 8 is 5 % slower)
 
 struct Box {
     float lo[3], hi[3];

@@ -20,8 +20,8 @@ def check(spheres, leaf=4):
 def test_random_spheres_scene(leaf):
     sc = scenes.random_spheres(500)
     nodes, levels, large = check(sc, leaf)
-    assert large == 1  # the ground sphere of radius 1000 gets no box
-    assert nodes >= (499 + leaf - 1) // leaf - 1
+    assert large == 4  # the ground sphere of radius 1000 and the three of radius 1 (5 x the median) get no box
+    assert nodes >= (496 + leaf - 1) // leaf - 1
     assert levels <= 28 + 9
 
 
@@ -39,7 +39,7 @@ def test_default_scene_and_tiny_scenes():
 def test_ten_thousand_spheres_and_depth_bound():
     sc = scenes.random_spheres(10000, grid_half=50, seed=7)
     nodes, levels, large = check(sc, 2)
-    assert large == 1 and levels <= 40 and nodes >= 4999
+    assert large == 4 and levels <= 40 and nodes >= 4997
 
 
 def test_degenerate_inputs_keep_depth_bounded():
