@@ -670,19 +670,78 @@ __device__ __forceinline__ void hit_frame(const RayState &r, float t, float cx, 
     }
 }
 
-// GeneratePointInUnitSphere, Source/main.cpp:398-414: one Philox block per attempt.
-__device__ __forceinline__ void point_in_unit_sphere(uint32_t pixel, uint32_t sample,
-                                                     uint32_t &call, uint32_t k0, uint32_t k1,
-                                                     float &x, float &y, float &z)
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long m);
+
+// GeneratePointInUnitSphere (Source/main.cpp:398-414) for the lanes of a wave that `want` a point,
+// one Philox block per attempt, with the lanes helping
+// each other.  A lane's attempts are the Philox blocks call, call + 1, ... of its own (pixel,
+// sample) stream, and it must take the FIRST one inside the sphere; which lane evaluates an
+// attempt does not matter.  Every lane tries its attempt 0 itself (52 % succeed).  The rest publish
+// their stream in LDS, and in each further round all 64 lanes evaluate `per` consecutive attempts
+// for each of them (per = the power of two that fits, at most 16); a lane takes its first success
+// and advances its counter past it, or past all `per` attempts if none succeeded.  Two rounds
+// usually do where the plain loop makes the wave wait for its unluckiest lane (five or six
+// attempts).  Must be called by all 64 lanes; `coop` = 192 words of LDS owned by the wave.
+__device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixel, uint32_t sample, uint32_t &call,
+                                                        uint32_t k0, uint32_t k1, uint32_t *coop, int lane,
+                                                        float &x, float &y, float &z)
 {
-    for (;;) {
+    bool need = want;
+    if (need) {
         uint32_t w[4];
         philox4x32_10(pixel, sample, call++, k0, k1, w);
         x = range_m1_p1(w[0]);
         y = range_m1_p1(w[1]);
         z = range_m1_p1(w[2]);
-        if (((x * x) + (y * y) + (z * z)) < 1.0f)
-            return;
+        need = !(((x * x) + (y * y) + (z * z)) < 1.0f);
+    }
+    unsigned long long nm = __ballot(need);
+    while (nm != 0ull) {
+        const uint32_t n = (uint32_t)__popcll(nm);
+        uint32_t lg = 31u - (uint32_t)__builtin_clz(64u / n);
+        lg = lg > 4u ? 4u : lg;
+        const uint32_t per = 1u << lg;
+        const uint32_t k = lane_rank(nm);
+        if (need) {
+            coop[k] = pixel;
+            coop[64u + k] = sample;
+            coop[128u + k] = call;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t t = (uint32_t)lane >> lg, at = (uint32_t)lane & (per - 1u);
+        float hx = 0.0f, hy = 0.0f, hz = 0.0f;
+        bool ok = false;
+        if (t < n) {
+            uint32_t w[4];
+            philox4x32_10(coop[t], coop[64u + t], coop[128u + t] + at, k0, k1, w);
+            hx = range_m1_p1(w[0]);
+            hy = range_m1_p1(w[1]);
+            hz = range_m1_p1(w[2]);
+            ok = ((hx * hx) + (hy * hy) + (hz * hz)) < 1.0f;
+        }
+        const unsigned long long okm = __ballot(ok);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t src = (uint32_t)lane;
+        bool got = false;
+        if (need) {
+            const uint32_t bits = (uint32_t)(okm >> (k << lg)) & ((1u << per) - 1u);
+            if (bits != 0u) {
+                const uint32_t first = (uint32_t)__builtin_ctz(bits);
+                src = (k << lg) + first;
+                call += first + 1u;
+                got = true;
+                need = false;
+            } else {
+                call += per;
+            }
+        }
+        const float gx = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src * 4u), __float_as_int(hx)));
+        const float gy = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src * 4u), __float_as_int(hy)));
+        const float gz = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src * 4u), __float_as_int(hz)));
+        if (got) {
+            x = gx; y = gy; z = gz;
+        }
+        nm = __ballot(need);
     }
 }
 
@@ -747,6 +806,11 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
     }
     // hierarchy scan: the nodes of a small tree live in LDS, behind the walk's stack
     float4 *bvh_lds = reinterpret_cast<float4 *>(stage) + (size_t)a.bvh.levels * (kTraceThreads / 4);
+    // 192 words per wave for unit_sphere_points_wave: the head of the wave's own operand staging
+    // slice in the list scans (idle while paths are shaded), or a region behind the hierarchy's nodes
+    uint32_t *coop = FILTER == kFilterBvh
+                         ? reinterpret_cast<uint32_t *>(bvh_lds + (size_t)a.bvh.lds_nodes * 4u) + (threadIdx.x >> 6) * 192
+                         : reinterpret_cast<uint32_t *>(stage) + (threadIdx.x >> 6) * (9 * 64);
     if (FILTER == kFilterBvh && a.bvh.lds_nodes) {
         for (uint32_t i = threadIdx.x; i < a.bvh.lds_nodes * 4u; i += blockDim.x)
             bvh_lds[i] = a.bvh.nodes[i];
@@ -906,6 +970,16 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
         if (wave_active)
             ++n_rounds;
 
+        // ---- the random point of the Diffuse and Metal branches (:566, :584), drawn for the
+        // whole wave at once; nothing else draws between the hit and this point
+        int material = -1;
+        if (shade && best >= 0)
+            material = a.spheres[best].material;
+        const bool wants_point = material == RT_MAT_DIFFUSE || material == RT_MAT_METAL;
+        float rx = 0.0f, ry = 0.0f, rz = 0.0f;
+        if (__any(wants_point))
+            unit_sphere_points_wave(wants_point, pixel, sample, call, a.key0, a.key1, coop, lane, rx, ry, rz);
+
         // ---- GetRayColor's branches, Source/main.cpp:562-597
         bool terminated = false;
         if (shade) {
@@ -920,7 +994,6 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                 terminated = true;
             } else {
                 const rt_sphere *sp = a.spheres + best;
-                const int material = sp->material;
                 const bool dielectric = EXT && (a.flags & RT_FLAG_DIELECTRIC) != 0u && material == RT_MAT_GLASS;
                 if (dielectric) {
                     // EXTENSION (RT_FLAG_DIELECTRIC; the reference's Glass is flat white, :594):
@@ -967,14 +1040,11 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                     if (depth <= 0)
                         terminated = true;
                 } else if (material == RT_MAT_DIFFUSE || material == RT_MAT_METAL) {
-                    float px, py, pz, nx, ny, nz, rx, ry, rz;
+                    float px, py, pz, nx, ny, nz;
                     bool inside;
                     hit_frame(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius,
                               px, py, pz, nx, ny, nz, inside);
                     float ndx, ndy, ndz;
-                    // both branches draw exactly one point, and nothing else draws in between
-                    // (:566, :584), so the divergent rejection loop runs once for all lanes
-                    point_in_unit_sphere(pixel, sample, call, a.key0, a.key1, rx, ry, rz);
                     if (material == RT_MAT_DIFFUSE) {
                         // S = Normal + GeneratePointInUnitSphere(), :566
                         ndx = nx + rx; ndy = ny + ry; ndz = nz + rz;
@@ -1194,7 +1264,8 @@ __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, u
 uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels, uint32_t bvh_lds_nodes)
 {
     if (filter == kFilterBvh)
-        return (bvh_levels ? bvh_levels : 1u) * kTraceThreads * (uint32_t)sizeof(uint32_t) + bvh_lds_nodes * 64u;
+        return (bvh_levels ? bvh_levels : 1u) * kTraceThreads * (uint32_t)sizeof(uint32_t) + bvh_lds_nodes * 64u +
+               4u * 192u * (uint32_t)sizeof(uint32_t);
     return 4u * 9u * 64u * (uint32_t)sizeof(float);
 }
 
