@@ -1,0 +1,63 @@
+"""Two processes, one device each in production; here both on GPU 0 with gloo carrying the reduce
+(RCCL needs one device per rank).  The real library traces each rank's share; the assembled frame
+must equal the single-process frame and the oracle's, for both partitionings."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle_lib as O
+import scenes
+
+W, H, SPP, DEPTH, SEED = 96, 54, 6, 8, 21
+
+
+def _worker(rank, world, port, partition, out_path):
+    import torch
+    import torch.distributed as dist
+
+    import dist_render
+    import rtamd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    ctx = rtamd.Context(0)
+    ctx.set_scene(scenes.random_spheres(500))
+    tracer = dist_render.DeviceTracer(ctx, rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA))
+    p = dist_render.rank_params(W, H, SPP, DEPTH, SEED, partition, rank, world)
+    sums = torch.zeros(W * H * 3, dtype=torch.int32, device="cuda")
+    rgb = torch.zeros(W * H * 3, dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        dist_render.trace_frame(tracer, p, sums, rgb, rank, world, dist)
+    torch.cuda.synchronize()
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, rgb.cpu().numpy().reshape(H, W, 3))
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("partition", ["samples", "tiles"])
+def test_two_processes_on_the_device_assemble_the_oracle_frame(tmp_path, partition):
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(2, _free_port(), partition, out), nprocs=2, join=True)
+    got = np.load(out)
+    sc = scenes.random_spheres(500)
+    want, _, _ = O.trace_tile(sc, O.camera(*scenes.RANDOM_SPHERES_CAMERA), W, H, SPP, DEPTH, O.RNG_COUNTER, seed=SEED)
+    assert np.array_equal(got, want)
