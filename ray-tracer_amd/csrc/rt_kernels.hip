@@ -7,21 +7,23 @@
 //     finished lanes from an 8x8-pixel chunk of (pixel, sample) items it pulls
 //     from a global queue (ballot + mbcnt ranks, no per-lane atomics), so waves
 //     never idle on short paths while long ones finish;
-//   * the sphere list is streamed through LDS in tiles of {cx, cy, cz, r*r};
-//     every lane reads the same record (LDS broadcast, conflict free);
-//   * the hot loop only decides, per sphere, whether the reference's
-//     `discriminant < 0` early-out CAN fail, and shifts the answer into a
-//     per-lane 32-bit candidate mask -- no branch, no sqrt, no divide.  It uses
-//     a conservative test evaluated with fused multiply-adds (12 instructions
-//     per sphere): it may flag a sphere the reference rejects, never the
-//     reverse (bound below, at filter_sign).  Candidates (a handful per ray) are
-//     then resolved in list order with the reference's exact, unfused
-//     arithmetic and root selection, so results are bit-identical;
+//   * a ray finds the spheres that need the reference's exact root evaluation through a
+//     CONSERVATIVE first phase, which may pass a sphere the reference rejects but never the
+//     reverse; whatever it passes is then resolved with the reference's exact, unfused
+//     arithmetic and root selection, so results are bit-identical whichever phase 1 runs:
+//       - a walk over a bounding-box hierarchy built on the host (boxes padded per ray by the
+//         reference's own rounding slack; bvh_closest_hit), the default from 64 spheres up;
+//       - the whole list, streamed through LDS tiles of {cx, cy, cz, r*r}, with a widened
+//         discriminant test on the FP32 matrix cores (scan_tile_matrix) or with fused
+//         multiply-adds on the vector ALU (filter_sign), collecting one bit per test;
+//       - the reference's own discriminant for every sphere;
 //   * colour is byte-quantised at every recursion level in the reference, so
 //     the iterative path records the spheres it bounced off in an LDS stack and
 //     replays the per-level byte arithmetic in reverse once it terminates;
-//   * samples are summed as integers with atomics, so any split of samples or
-//     tiles over devices gives bit-identical frames.
+//   * GeneratePointInUnitSphere's rejection loop is shared out over the wave: idle lanes
+//     evaluate attempts for the lanes still without a point (unit_sphere_points_wave);
+//   * samples are summed as integers -- per wave in LDS, flushed to the frame once per
+//     8x8 chunk -- so any split of samples or tiles over devices gives bit-identical frames.
 //
 // Build with -ffp-contract=off: every float multiply and add must round on its
 // own, as in the reference's x86-64 build; sqrt and divide are IEEE (hipcc's
