@@ -42,6 +42,34 @@ def variant(n, s):
     if n == 8:  # no refill arithmetic: every lane keeps its first pixel (timing only)
         return rep(s, "                const uint32_t s = item / (uint32_t)ch_npx;\n                const uint32_t p = item - s * (uint32_t)ch_npx;\n                const int ly = (int)(p / (uint32_t)ch_tw);\n                const int lx = (int)p - ly * ch_tw;",
                    "                const uint32_t s = item >> 6;\n                const uint32_t p = item & 63u;\n                const int ly = (int)(p >> 3);\n                const int lx = (int)(p & 7u);")
+    if n == 9:  # the always-tested spheres are tested twice
+        return rep(s, "                    bvh_begin(a.bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best);", """                    { int n2; uint32_t s2; float c2; int b2;
+                      bvh_begin(a.bvh, ray, 0.001f, n2, s2, c2, b2);
+                      if (b2 == 12345678) w_sp = s2; }
+                    bvh_begin(a.bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best);""")
+    if n == 11:  # the camera ray of a new path is formed twice
+        return rep(s, "                depth = a.max_depth; // >= 1", """                { RayState r2; camera_ray(a.cam, a.width, a.height, px + 1, py, (double)unit_float(w[1]),
+                             (double)unit_float(w[0]), r2);
+                  if (r2.four_a == 12345.0f) ray = r2; }
+                depth = a.max_depth; // >= 1""")
+    if n == 13:  # the random point is drawn twice
+        return rep(s, "        if (__any(wants_point))\n            unit_sphere_points_wave(", """        if (__any(wants_point)) {
+            uint32_t c2 = call; float x2 = 0.f, y2 = 0.f, z2 = 0.f;
+            unit_sphere_points_wave(wants_point, pixel, sample ^ 0x5555u, c2, a.key0, a.key1, coop, lane, x2, y2, z2);
+            if (x2 == 12345.0f) rx = y2 + z2 + (float)c2;
+        }
+        if (__any(wants_point))
+            unit_sphere_points_wave(""")
+    if n == 14:  # no per-sample LDS atomics (timing only: the frame stays black)
+        s = rep(s, "                atomicAdd(acc + acc_at + 0u, (uint32_t)cr);\n                atomicAdd(acc + acc_at + 1u, (uint32_t)cg);\n                atomicAdd(acc + acc_at + 2u, (uint32_t)cb);",
+                "                if (cr == 12345) atomicAdd(acc + acc_at + 0u, (uint32_t)(cr + cg + cb));")
+        return s
+    if n == 15:  # hit frame and scatter arithmetic twice
+        return rep(s, "                    float ndx, ndy, ndz;\n                    if (material == RT_MAT_DIFFUSE) {", """                    { float p2x, p2y, p2z, n2x, n2y, n2z; bool in2;
+                      hit_frame(ray, closest * 0.5f, sp->center[1], sp->center[0], sp->center[2], sp->radius, p2x, p2y, p2z, n2x, n2y, n2z, in2);
+                      if (n2x == 12345.0f) px = p2x + p2y + p2z + n2y + n2z; }
+                    float ndx, ndy, ndz;
+                    if (material == RT_MAT_DIFFUSE) {""")
     raise SystemExit(f"no variant {n}")
 
 
@@ -49,7 +77,7 @@ def main():
     src = open(os.path.join(CSRC, "rt_kernels.hip")).read()
     os.makedirs("/tmp/diag", exist_ok=True)
     procs = []
-    for n in [int(x) for x in sys.argv[1:]] or [1, 3, 4, 7, 8]:
+    for n in [int(x) for x in sys.argv[1:]] or [1, 3, 4, 9, 11, 13, 14, 15]:
         path = f"/tmp/diag/rt_kernels_d{n}.hip"
         open(path, "w").write(variant(n, src))
         out = os.path.join(ROOT, "tools", f"librt_diag{n}.so")
