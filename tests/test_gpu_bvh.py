@@ -120,3 +120,42 @@ def test_clustered_scene_with_wide_radius_spread(ctx):
     cam = ((0.0, 20.0, 150.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0)
     got = same_as_oracle(ctx, sc, cam, 128, 72, 3, 8, 6)
     assert (got != got[0, 0]).any()
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1e-3, 0.0), (50.0, 3e4), (1e4, -2e6)])
+def test_grazing_rays_agree_with_the_exact_scan(ctx, scale, offset):
+    """Rays aimed to pass a sphere at (1 + eps) radii from its centre, eps from -1e-4 to 1e-4 around the
+    point where the reference's float discriminant changes sign, from near and far origins: the
+    padded boxes must never cost a hit that the reference's own loop (exact scan) finds."""
+    rs = np.random.RandomState(int(scale * 7) % 1000 + 1)
+    n = 400
+    sc = np.zeros(n, dtype=rtamd.SPHERE_DTYPE)
+    sc["center"] = (rs.uniform(-10, 10, size=(n, 3)) * scale + offset).astype(np.float32)
+    sc["radius"] = (10.0 ** rs.uniform(-2, 0, size=n) * scale).astype(np.float32)
+    sc["material"] = rtamd.MAT_DIFFUSE
+    m = 200000
+    which = rs.randint(0, n, size=m)
+    c = sc["center"][which].astype(np.float64)
+    r = sc["radius"][which].astype(np.float64)
+    dist = r * 10.0 ** rs.uniform(0.1, 3.5, size=m)           # origin 1.3 .. 3000 radii away
+    u = rs.normal(size=(m, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    o = c + u * dist[:, None]
+    v = np.cross(u, rs.normal(size=(m, 3))); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    eps = rs.choice([0.0, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 3e-8, -3e-8], size=m)
+    b = r * (1.0 + eps)                                        # impact parameter
+    # direction from o to the point at distance b from the centre, perpendicular to the line of sight
+    foot = c + v * b[:, None]
+    d = foot - o
+    d *= (10.0 ** rs.uniform(-2, 2, size=m))[:, None]         # un-normalised, like the reference's rays
+    rays = np.concatenate([o, d], axis=1).astype(np.float32)
+    ctx.set_scene(sc)
+    try:
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_EXACT)
+        want = ctx.intersect(rays)
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_BVH)
+        got = ctx.intersect(rays)
+    finally:
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_BVH)
+    assert got.tobytes() == want.tobytes()
+    hit_target = (want["index"] == which).mean()
+    assert 0.2 < hit_target < 0.8  # the batch really straddles the edge
