@@ -1,0 +1,210 @@
+// rt_arith.h -- the reference's arithmetic, operation by operation (Source/main.cpp, cited per
+// function): random words to floats, bytes, rays, the discriminant and the root selection of
+// RaySphereIntersectionTest, the hit frame.  Device code; part of rt_kernels.hip's translation unit.
+//
+// Everything here relies on -ffp-contract=off: every float multiply and add rounds on its own, as
+// in the reference's x86-64 build; sqrt and divide are IEEE.
+#pragma once
+
+#include <limits.h>
+#include <math.h>
+
+#include "rt_device.h"
+
+namespace rtamd {
+namespace {
+
+// ---------------------------------------------------------------------------
+// Counter-based random numbers
+// ---------------------------------------------------------------------------
+
+// Philox4x32-10 block for counter (c0, c1, c2, 0).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4])
+{
+    uint32_t c3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        // one 32x32->64 multiply per product (v_mad_u64_u32), not separate high and low halves
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * (unsigned long long)c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * (unsigned long long)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// RandomFloat(), Source/main.cpp:87-92, as libstdc++ maps one 32-bit engine
+// word to [0,1): float(w) / 2^32, and 1.0f replaced by the float below it.
+__device__ __forceinline__ float unit_float(uint32_t w)
+{
+    return fminf((float)w * 0x1p-32f, 0.99999994f);
+}
+
+// RandomFloat(-1.0f, 1.0f), Source/main.cpp:94-97: -1 + 2*r evaluated in double, then
+// narrowed.  2*r - 1 is exact in double for every float r in [0,1), so the narrowing is
+// the only rounding -- which is exactly what one float fma computes.
+__device__ __forceinline__ float range_m1_p1(uint32_t w)
+{
+    return __builtin_fmaf(2.0f, unit_float(w), -1.0f);
+}
+
+// ---------------------------------------------------------------------------
+// Bytes
+// ---------------------------------------------------------------------------
+
+// static_cast<int>(float) as the reference's x86-64 build executes it (cvttss2si: truncate,
+// INT_MIN for NaN and out-of-range), then glm::clamp to 0..255 (Source/main.cpp:117-133).
+// INT_MIN clamps to 0, so the result is 0 for NaN, for v < 1 and for v >= 2^31, else
+// min(trunc(v), 255).  v_cvt_u32_f32 truncates and saturates (NaN and negatives to 0, large
+// values to 0xFFFFFFFF); read as signed, everything from 2^31 up is negative and clamps to 0.
+__device__ __forceinline__ int to_byte(float v)
+{
+    uint32_t u;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(v));
+    return min(max((int)u, 0), 255);
+}
+
+// GetGradientColorAtRay + Lerp, Source/main.cpp:461-467, 157-160.
+__device__ __forceinline__ void sky(float dy, int &r, int &g, int &b)
+{
+    const float t = dy * 1.8f;
+    const float omt = 1.0f - t;
+    r = to_byte(omt * 255.0f + t * 128.0f);
+    g = to_byte(omt * 255.0f + t * 178.0f);
+    b = to_byte(omt * 255.0f + t * 255.0f);
+}
+
+// EXTENSION (RT_FLAG_FLOAT_SHADING): colour limited to ToRGB's range but not truncated; NaN -> 0.
+__device__ __forceinline__ float limit_255(float v)
+{
+    return v > 0.0f ? (v < 255.0f ? v : 255.0f) : 0.0f;
+}
+
+__device__ __forceinline__ void sky_float(float dy, float &r, float &g, float &b)
+{
+    const float t = dy * 1.8f;
+    const float omt = 1.0f - t;
+    r = limit_255(omt * 255.0f + t * 128.0f);
+    g = limit_255(omt * 255.0f + t * 178.0f);
+    b = limit_255(omt * 255.0f + t * 255.0f);
+}
+
+// ---------------------------------------------------------------------------
+// Rays
+// ---------------------------------------------------------------------------
+
+struct RayState {
+    float ox, oy, oz, dx, dy, dz;
+    float four_a, two_a; // 4*dot(D,D), 2*dot(D,D)
+    float a_filter;      // dot(D,D) * (1 - 2^-17), the conservative filter's A
+    bool tame;           // all components finite and small enough for the filter's bound
+};
+
+// Magnitude limits under which the conservative filter's arithmetic can neither
+// overflow nor lose its margin to underflow (see filter_sign).
+constexpr float kTameMax = 0x1p28f;   // |coordinate|, |direction component|
+constexpr float kTameMinA = 0x1p-40f; // dot(D,D)
+
+__device__ __forceinline__ void ray_prepare(RayState &r)
+{
+    const float A = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz; // dot(): products summed left to right
+    r.four_a = 4.0f * A;
+    r.two_a = 2.0f * A;
+    r.a_filter = __builtin_fmaf(-0x1p-17f, A, A);
+    // the sum of magnitudes is NaN or Inf as soon as one component is, and comparisons with NaN
+    // are false: one test covers "finite" and "small enough" (it is a little stricter than a test
+    // per component, which only sends a few more rays to the exact scan)
+    const float m = ((fabsf(r.ox) + fabsf(r.oy)) + (fabsf(r.oz) + fabsf(r.dx))) + (fabsf(r.dy) + fabsf(r.dz));
+    r.tame = (m < kTameMax) && (A >= kTameMinA);
+}
+
+// Camera::GetRay, Source/main.cpp:440-444, for pixel (i, j) with jitter (ju, jv)
+// in [0,1): u and v are formed in double and narrowed (Source/main.cpp:627-628).
+__device__ __forceinline__ void camera_ray(const rt_camera &cam, uint32_t width, uint32_t height,
+                                           int i, int j, double ju, double jv, RayState &r)
+{
+    const float u = (float)(((double)(float)i + ju) / (double)(float)width);
+    const float v = (float)(((double)(float)j + jv) / (double)(float)height);
+    r.ox = cam.origin[0]; r.oy = cam.origin[1]; r.oz = cam.origin[2];
+    r.dx = ((cam.bottom_left[0] + (cam.horizontal[0] * u)) + (v * cam.vertical[0])) - cam.origin[0];
+    r.dy = ((cam.bottom_left[1] + (cam.horizontal[1] * u)) + (v * cam.vertical[1])) - cam.origin[1];
+    r.dz = ((cam.bottom_left[2] + (cam.horizontal[2] * u)) + (v * cam.vertical[2])) - cam.origin[2];
+    ray_prepare(r);
+}
+
+// Discriminant of RaySphereIntersectionTest, Source/main.cpp:475-479, with the
+// per-ray factors (A) and the per-sphere factor (R*R) computed once: the value
+// is bit-identical because each hoisted factor is a single rounded product.
+__device__ __forceinline__ float discriminant(const RayState &r, const Geom &s, float &B)
+{
+    const float ocx = r.ox - s.cx, ocy = r.oy - s.cy, ocz = r.oz - s.cz;
+    const float d = ocx * r.dx + ocy * r.dy + ocz * r.dz;
+    B = d + d; // float(2.0 * d): doubling is exact
+    const float C = (ocx * ocx + ocy * ocy + ocz * ocz) - s.r2;
+    return B * B - r.four_a * C;
+}
+
+// Root selection of RaySphereIntersectionTest, Source/main.cpp:481-500, against
+// the shrinking ClosestDistance of IntersectSceneSpheres (:539-545).  Returns
+// true when the sphere becomes the closest hit (an equal T is accepted, so the
+// later sphere wins a tie).
+__device__ __forceinline__ bool resolve_candidate(const RayState &r, const Geom &s, float tmin,
+                                                  float &closest)
+{
+    float B;
+    const float disc = discriminant(r, s, B);
+    if (disc < 0.0f)
+        return false;
+    const float sq = sqrtf(disc);
+    float root = (-B - sq) / r.two_a;
+    if (root < tmin || root > closest) {
+        root = (-B + sq) / r.two_a;
+        if (root < tmin || root > closest)
+            return false;
+    }
+    closest = root;
+    return true;
+}
+
+// Effective root of RaySphereIntersectionTest (Source/main.cpp:490-499) for a
+// ray without NaNs: the near root if it is >= tmin, else the far root.
+__device__ __forceinline__ void resolve_unordered(const RayState &r, const Geom &s, int idx, float tmin,
+                                                  float &closest, int &best)
+{
+    float B;
+    const float disc = discriminant(r, s, B);
+    if (disc < 0.0f)
+        return;
+    const float sq = sqrtf(disc);
+    float root = (-B - sq) / r.two_a;
+    if (root < tmin)
+        root = (-B + sq) / r.two_a;
+    if (root >= tmin && (root < closest || (root == closest && idx > best))) {
+        closest = root;
+        best = idx;
+    }
+}
+
+// Hit point and normal, Source/main.cpp:503-514.
+__device__ __forceinline__ void hit_frame(const RayState &r, float t, float cx, float cy, float cz,
+                                          float radius, float &px, float &py, float &pz, float &nx,
+                                          float &ny, float &nz, bool &inside)
+{
+    px = r.ox + (r.dx * t); py = r.oy + (r.dy * t); pz = r.oz + (r.dz * t);
+    nx = (px - cx) / radius; ny = (py - cy) / radius; nz = (pz - cz) / radius;
+    inside = (r.dx * nx + r.dy * ny + r.dz * nz) > 0.0f;
+    if (inside) {
+        nx = -nx; ny = -ny; nz = -nz;
+    }
+}
+
+
+} // namespace
+} // namespace rtamd

@@ -1,0 +1,225 @@
+// rt_bvh_walk.h -- IntersectSceneSpheres as a per-ray walk over the bounding-box hierarchy built by
+// rt_bvh.cpp; the spheres in the leaves it reaches get the reference's exact test.
+#pragma once
+
+#include "rt_arith.h"
+#include "rt_list_scan.h"
+
+namespace rtamd {
+namespace {
+
+// First half of resolve_unordered for a leaf record: the discriminant, and whether the root
+// evaluation can be skipped.  Besides the reference's own `Discriminant < 0` early-out, a sphere
+// with B > 0 and C > 0 (origin outside, centre behind) is dropped without a square root: then
+// 4AC > 0, so fl(B*B - 4AC) <= fl(B*B), its correctly rounded root is at most sqrt(fl(B*B)) = |B|,
+// both numerators -B -+ sq are <= 0 and the reference rejects both roots against tmin > 0.
+__device__ __forceinline__ bool leaf_candidate(const RayState &r, const Geom &s, float &B, float &disc)
+{
+    const float ocx = r.ox - s.cx, ocy = r.oy - s.cy, ocz = r.oz - s.cz;
+    const float d = ocx * r.dx + ocy * r.dy + ocz * r.dz;
+    B = d + d;
+    const float C = (ocx * ocx + ocy * ocy + ocz * ocz) - s.r2;
+    disc = B * B - r.four_a * C;
+    return !(disc < 0.0f) && !(B > 0.0f && C > 0.0f);
+}
+
+// Second half: the effective root (Source/main.cpp:490-499) and the closest-hit update; the
+// list index is fetched only when the root is in range.
+__device__ __forceinline__ void leaf_root(const RayState &r, float B, float disc, const uint32_t *index, float tmin,
+                                          float &closest, int &best)
+{
+    const float sq = sqrtf(disc);
+    float root = (-B - sq) / r.two_a;
+    if (root < tmin)
+        root = (-B + sq) / r.two_a;
+    if (root >= tmin && root <= closest) {
+        const int idx = (int)*index;
+        if (root < closest || idx > best) {
+            closest = root;
+            best = idx;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Hierarchy scan: a per-ray walk over boxes instead of a pass over the list
+// ---------------------------------------------------------------------------
+//
+// A conservative filter like the two above, with the ray deciding which part
+// of the list it looks at: spheres in leaves the walk does not reach are those
+// the reference cannot accept, the others go through resolve_unordered.
+//
+// Why skipping a box is safe.  Write oc for the reference's rounded O - C,
+// q = |oc|^2, and take its acceptance condition from filter_sign: the hit branch
+// is taken only if the line through C + oc along D passes within
+//     dist^2 <= r^2 + u (19.8 q + 5.2 r^2),                       u = 2^-24,
+// of the centre, and the root T it then accepts lies (with the roundings of A, B,
+// C, the square root and the division: |P - C|^2 <= r^2 + u (41 q + 25 r^2) for
+// P = O + T D) at a point whose distance from C is below
+//     r_eff = sqrt(r^2 (1 + 64u) + 64u q).
+// So the segment [tmin, closest] of the line meets the ball of radius r_eff at the
+// accepted T, hence also every box that contains the sphere's box once it is
+// padded by r_eff - |r|, which is largest for the smallest radius in the tree:
+//     pad >= sqrt(rmin^2 (1 + 64u) + 64u qmax) - rmin,   qmax = (|O - center| + radius)^2 >= q.
+// The slab test runs in coordinates relative to the tree's centre; its own
+// roundings move a plane by less than 8u (|O - center| + radius) and scale a t by
+// less than 1 + 4u, which an extra 2^-10 r_eff of padding (r_eff >= sqrt(64u qmax),
+// so this is at least 2^-19 sqrt(qmax) = 32u sqrt(qmax)), the factor 1.001 on the
+// whole and the 2^-20 relative slack on [tmin, closest] cover.  A direction component
+// too small to divide by is replaced by 2^-50 of the largest one: over any distance
+// inside the tree that moves the ray by less than 2^-49 of the tree's size.  Only
+// tame rays walk the tree.
+//
+// The walk is resumable.  Its per-ray state is (node, sp, closest, best) plus the ray's stack
+// column in LDS; a wave stops walking when no more than `suspend` of its lanes are still at it
+// (unless that was already so when it started), the finished rays go on to shading, and the
+// stragglers pick their walk up again in the wave's next pass, next to freshly started rays.
+// That cuts the tail of iterations a wave would spend with a handful of lanes active.
+// node: >= 0 inner node to visit, negative leaf code to process, kBvhDone when finished.
+constexpr int kBvhDone = INT_MIN;
+
+// Start of a ray's walk: the always-tested spheres, then the root.
+__device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, float tmin, int &node, uint32_t &sp,
+                                          float &closest, int &best)
+{
+    closest = INFINITY;
+    best = -1;
+    for (uint32_t i = 0; i < b.n_large; ++i)
+        resolve_unordered(r, b.leaf_geom[i], (int)b.leaf_index[i], tmin, closest, best);
+    node = b.n_nodes ? 0 : kBvhDone;
+    sp = 0u;
+}
+
+// Must be called by all 64 lanes; `walking` lanes hold a tame ray whose node is not kBvhDone.
+template <bool NODES_IN_LDS>
+__device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nodes, const RayState &r,
+                                         uint32_t *stk, bool walking, float tmin, int &node, uint32_t &sp,
+                                         float &closest, int &best)
+{
+    if (!walking)
+        node = kBvhDone;
+    const uint32_t n_start = (uint32_t)__popcll(__ballot(walking));
+    if (n_start == 0u)
+        return;
+    const uint32_t suspend = n_start > b.suspend_lanes ? b.suspend_lanes : 0u;
+
+    const float ox = r.ox - b.center[0], oy = r.oy - b.center[1], oz = r.oz - b.center[2];
+    // reach^2 = (|o| + radius)^2 <= 2 (|o|^2 + radius^2); the hardware square root (1 ulp) is
+    // inside the 1.001.  Since reff^2 >= 2^-18 reach^2, the slab roundings' 40u reach is below
+    // 2^-10 reff.
+    const float reach2 = 2.0f * __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, __builtin_fmaf(ox, ox, b.radius2)));
+    const float reff = __builtin_amdgcn_sqrtf(__builtin_fmaf(reach2, 0x1p-18f * (1.0f + 0x1p-10f), b.rmin2w));
+    const float pad = __builtin_fmaf(reff, 0x1.01p-10f, reff - b.rmin) * 1.001f;
+
+    const float dmax = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz));
+    const float dlim = dmax * 0x1p-50f;
+    const float ddx = fabsf(r.dx) < dlim ? copysignf(dlim, r.dx) : r.dx;
+    const float ddy = fabsf(r.dy) < dlim ? copysignf(dlim, r.dy) : r.dy;
+    const float ddz = fabsf(r.dz) < dlim ? copysignf(dlim, r.dz) : r.dz;
+    const float ix = __builtin_amdgcn_rcpf(ddx), iy = __builtin_amdgcn_rcpf(ddy), iz = __builtin_amdgcn_rcpf(ddz);
+    // t at plane p: (p - o) / d = fma(p, i, n); lower planes are moved by -pad, upper by +pad
+    const float nlx = -((ox + pad) * ix), nly = -((oy + pad) * iy), nlz = -((oz + pad) * iz);
+    const float nhx = -((ox - pad) * ix), nhy = -((oy - pad) * iy), nhz = -((oz - pad) * iz);
+    // Which of the two planes of an axis the ray meets first depends on the sign of d.  Instead
+    // of min/max per box (half-rate instructions), each t is fma(lo, a, fma(hi, b, c)) with one
+    // of a, b zero: the same single rounding, on full-rate instructions only.
+    const bool px = ix >= 0.0f, py = iy >= 0.0f, pz = iz >= 0.0f;
+    // entry plane: fma(lo, na, fma(hi, nb, nc)); exit plane: the same with na and nb swapped
+    const float nax = px ? ix : 0.0f, nbx = ix - nax, ncx = px ? nlx : nhx, fcx = px ? nhx : nlx;
+    const float nay = py ? iy : 0.0f, nby = iy - nay, ncy = py ? nly : nhy, fcy = py ? nhy : nly;
+    const float naz = pz ? iz : 0.0f, nbz = iz - naz, ncz = pz ? nlz : nhz, fcz = pz ? nhz : nlz;
+    const float fax = nbx, fbx = nax, fay = nby, fby = nay, faz = nbz, fbz = naz;
+    const float t_lo = tmin * (1.0f - 0x1p-20f);
+    float t_hi = closest * (1.0f + 0x1p-20f);
+
+    constexpr int kDone = kBvhDone;
+    while ((uint32_t)__popcll(__ballot(node != kDone)) > suspend) {
+        while (node >= 0) {
+            const float4 *np = (NODES_IN_LDS ? lds_nodes : b.nodes) + (size_t)node * 4u;
+            const float4 l0 = np[0], h0 = np[1], l1 = np[2], h1 = np[3];
+#define RT_SLAB(lo, hi, na, nb, nc) __builtin_fmaf(lo, na, __builtin_fmaf(hi, nb, nc))
+            const float n0 = fmaxf(fmaxf(fmaxf(RT_SLAB(l0.x, h0.x, nax, nbx, ncx), RT_SLAB(l0.y, h0.y, nay, nby, ncy)),
+                                         RT_SLAB(l0.z, h0.z, naz, nbz, ncz)), t_lo);
+            const float f0 = fminf(fminf(fminf(RT_SLAB(l0.x, h0.x, fax, fbx, fcx), RT_SLAB(l0.y, h0.y, fay, fby, fcy)),
+                                         RT_SLAB(l0.z, h0.z, faz, fbz, fcz)), t_hi);
+            const float n1 = fmaxf(fmaxf(fmaxf(RT_SLAB(l1.x, h1.x, nax, nbx, ncx), RT_SLAB(l1.y, h1.y, nay, nby, ncy)),
+                                         RT_SLAB(l1.z, h1.z, naz, nbz, ncz)), t_lo);
+            const float f1 = fminf(fminf(fminf(RT_SLAB(l1.x, h1.x, fax, fbx, fcx), RT_SLAB(l1.y, h1.y, fay, fby, fcy)),
+                                         RT_SLAB(l1.z, h1.z, faz, fbz, fcz)), t_hi);
+#undef RT_SLAB
+            const bool hit0 = n0 <= f0, hit1 = n1 <= f1;
+            const int c0 = __float_as_int(l0.w), c1 = __float_as_int(h0.w);
+            if (hit0 && hit1) {
+                const bool first0 = n0 <= n1;
+                stk[sp * kTraceThreads] = (uint32_t)(first0 ? c1 : c0);
+                ++sp;
+                node = first0 ? c0 : c1;
+            } else if (hit0) {
+                node = c0;
+            } else if (hit1) {
+                node = c1;
+            } else if (sp == 0u) {
+                node = kDone;
+            } else {
+                --sp;
+                node = (int)stk[sp * kTraceThreads];
+            }
+        }
+        if (node == kDone)
+            continue;
+        const uint32_t code = (uint32_t)~node, first = code >> 4, count = code & 15u;
+        for (uint32_t i0 = 0u; i0 < count; i0 += 4u) {
+            // up to four records in flight before the first is used; then every lane walks its
+            // own candidates, so the wave pays for the most candidates any lane has, not for
+            // every record some lane hits
+            Geom g[4];
+#pragma unroll
+            for (uint32_t j = 0u; j < 4u; ++j)
+                if (i0 + j < count)
+                    g[j] = b.leaf_geom[first + i0 + j];
+            float Bj[4], dj[4];
+            uint32_t cand = 0u;
+#pragma unroll
+            for (uint32_t j = 0u; j < 4u; ++j) {
+                Bj[j] = dj[j] = 0.0f;
+                if (i0 + j < count && leaf_candidate(r, g[j], Bj[j], dj[j]))
+                    cand |= 1u << j;
+            }
+            while (cand != 0u) {
+                const uint32_t j = (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1u;
+                const float Bs = j == 0u ? Bj[0] : j == 1u ? Bj[1] : j == 2u ? Bj[2] : Bj[3];
+                const float ds = j == 0u ? dj[0] : j == 1u ? dj[1] : j == 2u ? dj[2] : dj[3];
+                leaf_root(r, Bs, ds, b.leaf_index + (first + i0 + j), tmin, closest, best);
+            }
+        }
+        t_hi = closest * (1.0f + 0x1p-20f);
+        if (sp == 0u) {
+            node = kDone;
+        } else {
+            --sp;
+            node = (int)stk[sp * kTraceThreads];
+        }
+    }
+}
+
+// One whole walk for the one-ray-per-lane kernels (all 64 lanes call; `have` = this lane holds a
+// ray).  Rays outside the walk's preconditions take the reference's in-order loop from memory.
+__device__ __forceinline__ void closest_hit_by_hierarchy(const BvhArgs &b, const Geom *exact, uint32_t n,
+                                                         const RayState &r, bool have, uint32_t *stk,
+                                                         float &closest, int &best)
+{
+    int node = kBvhDone;
+    uint32_t sp = 0u;
+    if (have) {
+        if (r.tame)
+            bvh_begin(b, r, 0.001f, node, sp, closest, best);
+        else
+            scan_tile<kFilterExact>(exact, exact, n, 0u, r, 0.001f, closest, best);
+    }
+    bvh_walk<false>(b, nullptr, r, stk, have && node != kBvhDone, 0.001f, node, sp, closest, best);
+}
+
+
+} // namespace
+} // namespace rtamd

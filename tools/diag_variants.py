@@ -11,9 +11,16 @@ FLAGS = ("-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp3
          "-fno-fast-math -fno-slp-vectorize").split()
 
 
+SOURCES = ["rt_kernels.hip", "rt_arith.h", "rt_list_scan.h", "rt_bvh_walk.h"]
+
+
 def rep(s, a, b):
-    assert a in s, a[:60]
-    return s.replace(a, b)
+    """s: {file name: text}; replaces a by b in the one file that holds it."""
+    hits = [k for k in s if a in s[k]]
+    assert len(hits) == 1, (a[:60], hits)
+    out = dict(s)
+    out[hits[0]] = s[hits[0]].replace(a, b)
+    return out
 
 
 def variant(n, s):
@@ -61,9 +68,8 @@ def variant(n, s):
         if (__any(wants_point))
             unit_sphere_points_wave(""")
     if n == 14:  # no per-sample LDS atomics (timing only: the frame stays black)
-        s = rep(s, "                atomicAdd(acc + acc_at + 0u, (uint32_t)cr);\n                atomicAdd(acc + acc_at + 1u, (uint32_t)cg);\n                atomicAdd(acc + acc_at + 2u, (uint32_t)cb);",
+        return rep(s, "                atomicAdd(acc + acc_at + 0u, (uint32_t)cr);\n                atomicAdd(acc + acc_at + 1u, (uint32_t)cg);\n                atomicAdd(acc + acc_at + 2u, (uint32_t)cb);",
                 "                if (cr == 12345) atomicAdd(acc + acc_at + 0u, (uint32_t)(cr + cg + cb));")
-        return s
     if n == 15:  # hit frame and scatter arithmetic twice
         return rep(s, "                    float ndx, ndy, ndz;\n                    if (material == RT_MAT_DIFFUSE) {", """                    { float p2x, p2y, p2z, n2x, n2y, n2z; bool in2;
                       hit_frame(ray, closest * 0.5f, sp->center[1], sp->center[0], sp->center[2], sp->radius, p2x, p2y, p2z, n2x, n2y, n2z, in2);
@@ -74,15 +80,17 @@ def variant(n, s):
 
 
 def main():
-    src = open(os.path.join(CSRC, "rt_kernels.hip")).read()
-    os.makedirs("/tmp/diag", exist_ok=True)
+    src = {k: open(os.path.join(CSRC, k)).read() for k in SOURCES}
     procs = []
-    for n in [int(x) for x in sys.argv[1:]] or [1, 3, 4, 9, 11, 13, 14, 15]:
-        path = f"/tmp/diag/rt_kernels_d{n}.hip"
-        open(path, "w").write(variant(n, src))
+    for n in [int(x) for x in sys.argv[1:]] or [1, 3, 4, 11, 13, 14, 15]:
+        d = f"/tmp/diag/v{n}"
+        os.makedirs(d, exist_ok=True)
+        for k, text in variant(n, src).items():  # the patched copies shadow the originals (-I order)
+            open(os.path.join(d, k), "w").write(text)
         out = os.path.join(ROOT, "tools", f"librt_diag{n}.so")
-        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", *FLAGS, f"-I{ROOT}/include", f"-I{CSRC}", "-shared", "-o", out,
-                                       path, "-x", "hip", os.path.join(CSRC, "rt_capi.cpp"), os.path.join(CSRC, "rt_bvh.cpp")]))
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", *FLAGS, f"-I{ROOT}/include", f"-I{d}", f"-I{CSRC}", "-shared", "-o", out,
+                                       os.path.join(d, "rt_kernels.hip"), "-x", "hip", os.path.join(CSRC, "rt_capi.cpp"),
+                                       os.path.join(CSRC, "rt_bvh.cpp")]))
     sys.exit(max(p.wait() for p in procs))
 
 
