@@ -12,10 +12,10 @@
 //     reverse; whatever it passes is then resolved with the reference's exact, unfused
 //     arithmetic and root selection, so results are bit-identical whichever phase 1 runs:
 //       - a walk over a bounding-box hierarchy built on the host (boxes padded per ray by the
-//         reference's own rounding slack; bvh_closest_hit), the default from 64 spheres up;
+//         reference's own rounding slack; rt_bvh_walk.h), the default from 64 spheres up;
 //       - the whole list, streamed through LDS tiles of {cx, cy, cz, r*r}, with a widened
-//         discriminant test on the FP32 matrix cores (scan_tile_matrix) or with fused
-//         multiply-adds on the vector ALU (filter_sign), collecting one bit per test;
+//         discriminant test on the FP32 matrix cores or with fused
+//         multiply-adds on the vector ALU (rt_list_scan.h), collecting one bit per test;
 //       - the reference's own discriminant for every sphere;
 //   * colour is byte-quantised at every recursion level in the reference, so
 //     the iterative path records the spheres it bounced off in an LDS stack and
