@@ -103,7 +103,8 @@ enum {
 
 typedef struct rt_stats {
     uint64_t rays;            /* IntersectSceneSpheres calls (Source/main.cpp:562) since the last reset */
-    uint64_t sphere_tests;    /* rays x sphere count */
+    uint64_t sphere_tests;    /* rays x sphere count: the tests the reference's loop performs for these rays
+                                 (Source/main.cpp:534), not the number the chosen scan executed */
     uint64_t wave_passes;     /* passes of a 64-lane wave over the sphere list; rays / (64 * wave_passes)
                                  is the fraction of lanes that carried a ray */
     double   last_kernel_ms;  /* device time of the last synchronous call's kernels */
