@@ -41,7 +41,7 @@ struct rt_context {
     // host copies kept for the hierarchy, which is built on first use
     std::vector<rt_sphere> h_spheres;
     std::vector<Geom> h_exact;
-    BvhHost bvh;                   // without the node / record arrays once they are on the device
+    BvhHost bvh;                   // host copy of what d_bvh_* hold
     bool bvh_ready = false;
     int bvh_leaf_max = 4;
     uint32_t bvh_suspend_lanes = 16;  // see RT_OPT_BVH_SUSPEND_LANES
@@ -166,6 +166,11 @@ int ensure_bvh(rt_context *ctx)
     bvh_build(ctx->h_spheres.data(), ctx->h_exact.data(), ctx->n_spheres, ctx->bvh_leaf_max, b);
     if (b.levels > 96u)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "hierarchy deeper than 96 levels");
+    // the kernels follow child references and leaf ranges without bounds checks: make sure on the
+    // host that every one of them is in range before anything is launched
+    const std::string why = bvh_validate(ctx->h_spheres.data(), ctx->n_spheres, b);
+    if (!why.empty())
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "hierarchy failed its structural check: " + why);
     const size_t nb = std::max<size_t>(b.nodes.size(), 1) * sizeof(BvhNode);
     const size_t gb = std::max<size_t>(b.leaf_geom.size(), 1) * sizeof(Geom);
     const size_t ib = std::max<size_t>(b.leaf_index.size(), 1) * sizeof(uint32_t);
@@ -278,9 +283,16 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     a.aux_bytes = trace_aux_bytes(a.filter, a.bvh.levels, a.bvh.lds_nodes);
 
     a.stack_entry_bytes = a.n <= 65536u ? 2u : 4u;
-    const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
+    size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
+    if (lds > 64u * 1024u && a.bvh.lds_nodes != 0u) {
+        // a copy of the nodes this large would leave room for one or two workgroups per CU:
+        // walk them through the caches instead
+        a.bvh.lds_nodes = 0u;
+        a.aux_bytes = trace_aux_bytes(a.filter, a.bvh.levels, 0u);
+        lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
+    }
     if (lds > 160u * 1024u)
-        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_depth too large for the LDS bounce stack");
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_depth too large: the bounce stack does not fit in LDS");
     int per_cu = 0;
     RT_HIP(ctx, trace_occupancy(a.filter, lds, &per_cu));
     if (per_cu < 1)
