@@ -36,6 +36,9 @@
 namespace rtamd {
 namespace {
 
+// Lists up to this long are scanned by the reference's plain loop in the vector-scan kernel.
+constexpr uint32_t kShortList = 12u;
+
 // The bounce stack holds list indices: two bytes per entry while the list has at most 65536
 // spheres, else four.
 __device__ __forceinline__ void push_bounce(uint32_t *stack, uint32_t entry_bytes, int at, uint32_t index)
@@ -322,7 +325,15 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                 if (active && !ray.tame) // NaN, Inf, zero or huge rays: the reference's in-order loop
                     scan_tile<kFilterExact>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best);
             } else if (active) {
-                scan_tile<FILTER>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best);
+                if (FILTER == kFilterConservative && !MULTI_TILE && cnt <= kShortList) {
+                    // a handful of spheres (the reference's own scene has four): its loop as it
+                    // stands, :534-546 -- cheaper than a 32-record filter block that is mostly padding
+                    for (uint32_t i = 0u; i < cnt; ++i)
+                        if (resolve_candidate(ray, tile_e[i], 0.001f, closest))
+                            best = (int)i;
+                } else {
+                    scan_tile<FILTER>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best);
+                }
             }
         }
         if (wave_active)
