@@ -159,3 +159,32 @@ def test_grazing_rays_agree_with_the_exact_scan(ctx, scale, offset):
     assert got.tobytes() == want.tobytes()
     hit_target = (want["index"] == which).mean()
     assert 0.2 < hit_target < 0.8  # the batch really straddles the edge
+
+
+def test_random_scenes_every_scan_gives_the_exact_scans_frame(ctx):
+    """60 random scenes (1..3000 spheres; boxes, planes, lines, clusters; scales 1e-3..1e4, far
+    offsets, giants, duplicates, negative radii, extension flags): vector filter, matrix filter and
+    hierarchy reproduce the frame and the ray count of the reference's own discriminant scan."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_scans
+
+    try:
+        for seed in range(5000, 5060):
+            rs = np.random.RandomState(seed)
+            sc, cam = fuzz_scans.random_scene(rs)
+            p = rtamd.params(96, 54, 3, int(rs.choice([1, 4, 8])), seed=seed,
+                             flags=int(rs.choice([0, 0, rtamd.FLAG_DIELECTRIC])))
+            c = rtamd.make_camera(*cam)
+            ctx.set_scene(sc)
+            frames, rays = [], []
+            for filt in (rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX, rtamd.FILTER_BVH):
+                ctx.set_option(rtamd.OPT_FILTER, filt)
+                ctx.reset_stats()
+                frames.append(ctx.render(c, p))
+                rays.append(ctx.stats().rays)
+            assert all(np.array_equal(frames[0], f) for f in frames[1:]), seed
+            assert len(set(rays)) == 1, seed
+    finally:
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_BVH)
