@@ -80,3 +80,66 @@ def test_accepted_line_passes_within_the_discriminant_bound():
         h = (ocd * dd).sum(axis=1)
         line2 = q - h * h / (dd * dd).sum(axis=1)
         assert np.all(line2[acc] <= rd[acc] ** 2 + U * (19.8 * q[acc] + 5.2 * rd[acc] ** 2))
+
+
+def _fma(a, b, c):
+    """float32 fused multiply-add: the product of two float32 is exact in float64."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F)
+
+
+def slab_hit(o, d, lo, hi, center, radius2, rmin, rmin2w, t_hi, rcp_bias):
+    """The padded slab test of the hierarchy walk (rt_bvh_walk.h), operation by operation in float32.
+    rcp_bias perturbs the hardware reciprocal and square root by one unit in the last place."""
+    with np.errstate(all="ignore"):
+        ox, oy, oz = [(o[:, k] - center[k]).astype(F) for k in range(3)]
+        reach2 = (F(2.0) * _fma(oz, oz, _fma(oy, oy, _fma(ox, ox, np.full_like(ox, radius2))))).astype(F)
+        k = F(2.0 ** -18 * (1.0 + 2.0 ** -10))
+        reff = (np.sqrt(_fma(reach2, np.full_like(ox, k), np.full_like(ox, rmin2w))) * F(1.0 - rcp_bias * 2.0 ** -23)).astype(F)
+        pad = (_fma(reff, np.full_like(ox, F(1.00390625 * 2.0 ** -10)), (reff - F(rmin)).astype(F)) * F(1.001)).astype(F)
+        dmax = np.maximum(np.maximum(np.abs(d[:, 0]), np.abs(d[:, 1])), np.abs(d[:, 2]))
+        dlim = (dmax * F(2.0 ** -50)).astype(F)
+        tn = np.full(len(o), -np.inf, dtype=F)
+        tf = np.full(len(o), np.inf, dtype=F)
+        for kk, ok in enumerate((ox, oy, oz)):
+            dk = np.where(np.abs(d[:, kk]) < dlim, np.copysign(dlim, d[:, kk]), d[:, kk]).astype(F)
+            inv = ((F(1.0) / dk) * F(1.0 + rcp_bias * 2.0 ** -23)).astype(F)
+            nl = (-((ok + pad).astype(F) * inv)).astype(F)
+            nh = (-((ok - pad).astype(F) * inv)).astype(F)
+            pos = inv >= 0
+            zero = np.zeros_like(inv)
+            na = np.where(pos, inv, zero); nb = (inv - na).astype(F)
+            nc = np.where(pos, nl, nh); fc = np.where(pos, nh, nl)
+            t_in = _fma(lo[:, kk], na, _fma(hi[:, kk], nb, nc))
+            t_out = _fma(lo[:, kk], nb, _fma(hi[:, kk], na, fc))
+            tn = np.maximum(tn, t_in)
+            tf = np.minimum(tf, t_out)
+        tn = np.maximum(tn, F(0.001 * (1.0 - 2.0 ** -20)))
+        tf = np.minimum(tf, t_hi)
+        return tn <= tf
+
+
+def test_padded_box_is_met_wherever_the_reference_accepts():
+    """The sphere's own box (the tightest box the hierarchy can hold it in), padded as the walk pads
+    it and tested with the walk's arithmetic over [tmin, accepted root]: never a miss."""
+    rs = np.random.RandomState(9)
+    checked = 0
+    for scale, offset in ((1.0, 0.0), (1e-3, 0.0), (30.0, 2e4), (1e4, -3e6)):
+        o, d, c, r = grazing_batch(rs, 300000, scale, offset)
+        acc, T, _ = reference_roots(o, d, c, r)
+        tame = (np.abs(o).sum(axis=1) + np.abs(d).sum(axis=1) < 2.0 ** 28) & ((d.astype(np.float64) ** 2).sum(axis=1) >= 2.0 ** -40)
+        sel = acc & tame
+        o, d, c, r, T = o[sel], d[sel], c[sel], r[sel], T[sel]
+        center = np.array([offset, offset, offset], dtype=F) + F(0.37 * scale)   # any point serves
+        rel = c.astype(np.float64) - center.astype(np.float64)
+        radius = float(np.sqrt((rel * rel).sum(axis=1)).max()) * (1 + 1e-6)
+        radius2 = np.nextafter(F(radius) * F(radius), F(np.inf))
+        rmin = float(r.min())
+        rmin2w = np.nextafter(F(rmin * rmin * (1 + 2.0 ** -18)), F(np.inf))
+        lo = np.nextafter((rel - r[:, None].astype(np.float64)).astype(F), F(-np.inf))
+        hi = np.nextafter((rel + r[:, None].astype(np.float64)).astype(F), F(np.inf))
+        t_hi = (T * F(1.0 + 2.0 ** -20)).astype(F)
+        for bias in (-1.0, 0.0, 1.0):
+            hit = slab_hit(o, d, lo, hi, center, radius2, np.nextafter(F(rmin), F(-np.inf)), rmin2w, t_hi, bias)
+            assert hit.all(), (scale, offset, bias, int((~hit).sum()))
+        checked += len(o)
+    assert checked > 500000
