@@ -143,3 +143,75 @@ def test_padded_box_is_met_wherever_the_reference_accepts():
             assert hit.all(), (scale, offset, bias, int((~hit).sum()))
         checked += len(o)
     assert checked > 500000
+
+
+def _dot32(a, b):
+    return ((a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]) + a[:, 2] * b[:, 2]).astype(F)
+
+
+def _tame_accepted(rs, m, scale, offset):
+    o, d, c, r = grazing_batch(rs, m, scale, offset)
+    acc, T, _ = reference_roots(o, d, c, r)
+    tame = (np.abs(o).sum(axis=1) + np.abs(d).sum(axis=1) < 2.0 ** 28) & ((d.astype(np.float64) ** 2).sum(axis=1) >= 2.0 ** -40)
+    sel = acc & tame
+    return o[sel], d[sel], c[sel], r[sel]
+
+
+def _widened_r2(r):
+    rr = (r * r).astype(F)
+    wide = (rr + (rr * F(2.0 ** -16)).astype(F)).astype(F)
+    return np.nextafter(wide, F(np.inf))
+
+
+def test_vector_filter_never_rejects_what_the_reference_accepts():
+    """filter_sign (rt_list_scan.h) in float32 with emulated fused multiply-adds: s >= 0 for every
+    (ray, sphere) pair the reference's own discriminant accepts."""
+    rs = np.random.RandomState(10)
+    n = 0
+    for scale, offset in ((1.0, 0.0), (1e-3, 0.0), (30.0, 2e4), (1e4, -3e6)):
+        o, d, c, r = _tame_accepted(rs, 300000, scale, offset)
+        with np.errstate(all="ignore"):
+            oc = (o - c).astype(F)
+            A = _dot32(d, d)
+            a_filter = _fma(np.full_like(A, F(-2.0 ** -17)), A, A)
+            dd = _fma(oc[:, 2], d[:, 2], _fma(oc[:, 1], d[:, 1], (oc[:, 0] * d[:, 0]).astype(F)))
+            cc = _fma(oc[:, 0], oc[:, 0], _fma(oc[:, 1], oc[:, 1], _fma(oc[:, 2], oc[:, 2], -_widened_r2(r))))
+            s = _fma(dd, dd, -(a_filter * cc).astype(F))
+        assert not np.signbit(s).any(), (scale, offset, int(np.signbit(s).sum()))
+        n += len(o)
+    assert n > 500000
+
+
+def test_matrix_filter_never_rejects_what_the_reference_accepts():
+    """The two 4-term products of the matrix-core scan as k-ordered fused chains (what
+    v_mfma_f32_16x16x4_f32 computes), with the host's {C - T, K} records: d*d + e >= 0 for every
+    accepted pair, for shifts T inside and at the edge of the scene."""
+    rs = np.random.RandomState(11)
+    n = 0
+    for scale, offset in ((1.0, 0.0), (1e-3, 0.0), (30.0, 2e4), (1e4, -3e6)):
+        o, d, c, r = _tame_accepted(rs, 300000, scale, offset)
+        for shift_at in (0.0, 9.0):
+            T = (np.array([offset] * 3) + shift_at * scale).astype(F)
+            with np.errstate(all="ignore"):
+                cs = (c - T).astype(F)                                    # host: fl(C - shift)
+                cs64 = cs.astype(np.float64)
+                K = ((cs64 * cs64).sum(axis=1) * (1.0 - 2.0 ** -18) - _widened_r2(r).astype(np.float64)).astype(F)
+                os_ = (o - T).astype(F)                                   # device: matrix_operands
+                od = _fma(os_[:, 2], d[:, 2], _fma(os_[:, 1], d[:, 1], (os_[:, 0] * d[:, 0]).astype(F)))
+                oo = _fma(os_[:, 2], os_[:, 2], _fma(os_[:, 1], os_[:, 1], (os_[:, 0] * os_[:, 0]).astype(F)))
+                A = _dot32(d, d)
+                ap = _fma(np.full_like(A, F(-2.0 ** -17)), A, A)
+                ap2 = (ap + ap).astype(F)
+                c2 = (-(ap * oo).astype(F) * F(1.0 - 2.0 ** -18)).astype(F)
+                dacc = np.zeros_like(A)
+                for k in range(3):
+                    dacc = _fma(cs[:, k], -d[:, k], dacc)
+                dacc = _fma(np.ones_like(A), od, dacc)
+                eacc = c2
+                for k in range(3):
+                    eacc = _fma(cs[:, k], (ap2 * os_[:, k]).astype(F), eacc)
+                eacc = _fma(K, -ap, eacc)
+                s = _fma(dacc, dacc, eacc)
+            assert not np.signbit(s).any(), (scale, offset, shift_at, int(np.signbit(s).sum()))
+            n += len(o)
+    assert n > 1000000
