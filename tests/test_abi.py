@@ -59,3 +59,19 @@ def test_null_arguments_are_rejected_without_a_device():
     assert lib.rt_camera_init(None, None, None, 1.0, None) == -1
     assert lib.rt_create(0, None) == -1
     assert lib.rt_destroy(None) == -1
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 and as C++11, and a program in plain
+    C must link against the library (no C++ or torch types anywhere in the signatures)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "rt_mi355x.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+    exe = str(tmp_path / "render_c_abi")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "render_c_abi.c"), "-L", os.path.join(root, "ray-tracer_amd"),
+                           "-lrt_mi355x", "-o", exe])
+    assert os.path.exists(exe)
