@@ -11,7 +11,7 @@ rank 0 (the frame's only exchange step), and rank 0 divides by spp and packs RGB
 bit-identical to the single-GPU one.
 
 The tracer is duck-typed (`accumulate(params, sums)`, `resolve(sums, spp, rgb)`) so the CPU tests can
-drive this logic over gloo with the oracle standing in for the device.
+drive this logic over gloo with a CPU tracer standing in for the device.
 """
 import rtamd
 

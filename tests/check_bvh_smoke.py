@@ -1,5 +1,8 @@
+"""Two small frames through the hierarchy scan against the oracle: the first thing to run on a
+device after touching the walk (python tests/check_bvh_smoke.py)."""
 import os, sys
-sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/ray-tracer_amd/python")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "ray-tracer_amd", "python"))
 import numpy as np, torch, rtamd, scenes, oracle_lib as O
 ctx = rtamd.Context(0)
 for sc, cam in ((rtamd.default_scene(), scenes.DEFAULT_CAMERA), (scenes.random_spheres(500), scenes.RANDOM_SPHERES_CAMERA)):
