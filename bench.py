@@ -54,7 +54,7 @@ def cpu_baseline(scene):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    x0, xs = 948, 24  # 24 centre columns x 1080 rows x 64 spp = 1.66 M samples
+    x0, xs = 928, 64  # 64 centre columns x 1080 rows x 64 spp = 4.4 M samples: about 12 s on one core
     sample = f"columns {x0}..{x0 + xs - 1} of the 1920x1080/64spp/depth-8 frame, all rows, 1 thread, mt19937 stream"
     ocam = O.camera(*scenes.RANDOM_SPHERES_CAMERA)
     t0 = time.time()
@@ -79,7 +79,7 @@ def cpu_baseline(scene):
     rgb = np.zeros((H, W, 3), dtype=np.uint8)
     r = C.c_uint64(0)
     t0 = time.time()
-    O.lib().orc_trace_scene_threads(scene.ctypes.data, len(scene), C.byref(ocam), W, H, SPP, DEPTH, x0 - 4 * threads,
+    O.lib().orc_trace_scene_threads(scene.ctypes.data, len(scene), C.byref(ocam), W, H, SPP, DEPTH, W // 2 - 4 * threads,
                                     8 * threads, threads, rgb.ctypes.data, C.byref(r))
     mt_s = time.time() - t0
     out["port_threads"] = {"value": r.value / mt_s / 1e6, "cores": threads,
