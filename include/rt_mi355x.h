@@ -21,9 +21,10 @@
  *     without synchronising; the others return when the output is in host memory;
  *   - images are tightly packed RGB8, index (x + y*width)*3, row 0 = BOTTOM of
  *     the picture, exactly g_PixelData's layout (Source/main.cpp:76, 273-281);
- *   - calls on one context must not overlap in time (the reference calls its
- *     seam from four threads at once, Source/main.cpp:654; a host that wants
- *     that makes one full-frame call, or serialises tile calls).
+ *   - the reference calls its seam from four threads at once on disjoint tiles
+ *     (Source/main.cpp:654): entry points taking a context lock it, so concurrent
+ *     calls on one context are safe and run one after another (the _device entry
+ *     points still only enqueue; rt_destroy must not race with anything).
  */
 #ifndef RT_MI355X_H
 #define RT_MI355X_H

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -64,6 +65,9 @@ struct rt_context {
 
     double last_kernel_ms = 0.0, last_wall_ms = 0.0;
     std::string error;
+    // The reference calls its seam from four threads at once (TraceScene, Source/main.cpp:647-659):
+    // entry points on one context take this lock, so such calls are safe and run one after another.
+    std::recursive_mutex mtx;
 };
 
 namespace {
@@ -389,6 +393,7 @@ int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n)
 {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     if (n && !spheres)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null sphere list");
     if (n > (1u << 24))
@@ -515,6 +520,9 @@ int rt_camera_init(const float lookfrom[3], const float lookat[3], const float u
 int rt_accumulate_device(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
                          int ystart, int xsize, int ysize, uint32_t *d_sums, void *stream)
 {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     int st = check_params(ctx, cam, params);
     if (st != RT_OK)
         return st;
@@ -531,6 +539,7 @@ int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, u
 {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     if (!d_sums || !d_rgb || width == 0 || height == 0 || spp_div == 0)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad resolve arguments");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -549,6 +558,9 @@ int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, u
 int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
                      int ystart, int xsize, int ysize, uint8_t *d_rgb, void *stream)
 {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     int st = check_params(ctx, cam, params);
     if (st != RT_OK)
         return st;
@@ -580,6 +592,9 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *par
 int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart, int ystart,
               int xsize, int ysize, uint8_t *rgb)
 {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     int st = check_params(ctx, cam, params);
     if (st != RT_OK)
         return st;
@@ -627,6 +642,9 @@ int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params
                           int ystart, int xsize, int ysize, uint8_t *rgb, uint32_t samples_per_pass,
                           rt_progress_fn progress, void *user)
 {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     int st = check_params(ctx, cam, params);
     if (st != RT_OK)
         return st;
@@ -678,6 +696,7 @@ int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width
 {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     if (!cam || !d_hits || width == 0 || height == 0)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad primary-hit arguments");
     if (!ctx->have_scene)
@@ -704,6 +723,7 @@ int rt_primary_hits(rt_context *ctx, const rt_camera *cam, uint32_t width, uint3
 {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     if (!hits)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null hits");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -731,6 +751,7 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out)
 {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     if (!ctx->have_scene)
         return fail(ctx, RT_ERR_NO_SCENE, "rt_set_scene has not been called");
     if (n == 0)
@@ -777,6 +798,7 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
 {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     switch (option) {
     case RT_OPT_FILTER:
         if (value == 0) ctx->filter = kFilterExact;
@@ -854,6 +876,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *stats)
 {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     if (!stats)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null stats");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -872,6 +895,7 @@ int rt_reset_stats(rt_context *ctx)
 {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipDeviceSynchronize());
     RT_HIP(ctx, hipMemset(ctx->d_rays, 0, 2 * sizeof(unsigned long long)));

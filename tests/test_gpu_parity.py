@@ -253,6 +253,36 @@ def test_sub_tile_leaves_rest_of_frame_untouched(ctx):
     assert np.array_equal(img, full)
 
 
+def test_four_threads_call_the_seam_at_once_like_tracescene(ctx):
+    """TraceScene (Source/main.cpp:647-659) starts four threads that each call
+    TraceThreadFunction on a quarter of the columns, at the same time, into the same buffer."""
+    import threading
+
+    sc = c3_scene()
+    ctx.set_scene(sc)
+    W, H = 128, 72
+    cam, p = rtamd.make_camera(*C3_CAM), rtamd.params(W, H, 4, 8, seed=13)
+    want = ctx.render(cam, p)
+    img = np.full((H, W, 3), 255, dtype=np.uint8)
+    errors = []
+
+    def strip(i):
+        try:
+            ctx.render(cam, p, tile=(i * (W // 4), 0, W // 4, H), rgb=img)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    for _ in range(3):
+        img[:] = 255
+        threads = [threading.Thread(target=strip, args=(i,)) for i in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors
+        assert np.array_equal(img, want)
+
+
 def test_sample_slices_and_interleaved_tiles_are_partition_invariant(ctx, torch):
     sc = c3_scene()
     ctx.set_scene(sc)
