@@ -47,6 +47,7 @@ struct rt_context {
     int bvh_leaf_max = 4;
     uint32_t bvh_suspend_lanes = 16;  // see RT_OPT_BVH_SUSPEND_LANES
     uint32_t bvh_lds_nodes_max = 512; // trees up to this many nodes (64 B each) are walked in LDS
+    uint32_t chunks_per_wave = 16; // work queue: split tiles' samples until there are this many chunks per resident wave
     uint32_t bvh_auto_min = 64;    // automatic choice: hierarchy from this many spheres up (measured crossover)
     float4 *d_bvh_nodes = nullptr;
     Geom *d_bvh_geom = nullptr;
@@ -306,6 +307,27 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     // every workgroup's 4 waves pull chunks until the queue is empty, so the grid
     // only needs to fill the chip
     uint32_t n_wg = (uint32_t)ctx->n_cus * (uint32_t)per_cu;
+    // A chunk is owned by one wave.  A call with few tiles per resident wave (a small frame, or
+    // one rank's share of a frame) would leave waves idle or the last ones running alone, so its
+    // tiles' sample ranges are cut into segments of at least kMinSegment samples, each a chunk.
+    a.segments = 1u;
+    a.seg_samples = a.sample_count;
+    {
+        const uint64_t wanted = (uint64_t)ctx->chunks_per_wave * 4u * n_wg;
+        const uint32_t kMinSegment = 4u;
+        if (wanted > a.n_chunks && a.sample_count >= 2u * kMinSegment) {
+            const uint64_t s_wanted = (wanted + a.n_chunks - 1u) / a.n_chunks;
+            uint32_t per = (uint32_t)((a.sample_count + s_wanted - 1u) / s_wanted);
+            if (per < kMinSegment)
+                per = kMinSegment;
+            const uint32_t segs = (a.sample_count + per - 1u) / per; // every segment non-empty
+            if (segs > 1u && (uint64_t)a.n_chunks * segs <= 0x7fffffffull) {
+                a.segments = segs;
+                a.seg_samples = per;
+                a.n_chunks *= segs;
+            }
+        }
+    }
     const uint32_t by_chunks = (a.n_chunks + 3u) / 4u;
     if (n_wg > by_chunks)
         n_wg = by_chunks;
@@ -838,6 +860,11 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
         if (value < 0 || value > 63)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_SUSPEND_LANES takes 0..63");
         ctx->bvh_suspend_lanes = (uint32_t)value;
+        return RT_OK;
+    case RT_OPT_CHUNKS_PER_WAVE:
+        if (value < 0 || value > 256)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_CHUNKS_PER_WAVE takes 0..256");
+        ctx->chunks_per_wave = (uint32_t)value;
         return RT_OK;
     case RT_OPT_BVH_MIN_SPHERES:
         if (value < 1 || value > (1ll << 30))

@@ -63,7 +63,11 @@ struct TraceArgs {
     uint32_t key0, key1;
     int32_t x0, y0, w, h;      // traced region
     uint32_t tiles_x, tiles_y; // 8x8 tiles of the region
-    uint32_t tile_first, tile_stride, n_chunks; // chunk c traces tile tile_first + c*tile_stride
+    uint32_t tile_first, tile_stride; // the call's tiles: tile_first + k*tile_stride
+    // Work queue: chunk c carries segment c % segments of tile k = c / segments, i.e. samples
+    // [seg*seg_samples, min(sample_count, (seg+1)*seg_samples)) of that tile's pixels.  Every
+    // segment is non-empty.  With segments > 1 several waves add into the same pixels of `sums`.
+    uint32_t n_chunks, segments, seg_samples;
     uint32_t *sums;            // full frame uint32 x3
     unsigned long long *rays;  // [0] ray counter, [1] wave passes over the sphere list
     uint32_t *chunk_counter;   // work queue head, zeroed before launch

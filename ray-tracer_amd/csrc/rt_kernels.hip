@@ -178,9 +178,10 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
         __syncthreads();
     }
 
-    // Per-wave colour sums of the (at most two) chunks the wave has paths in flight for.  A
-    // chunk's 64 pixels belong to this wave alone during the launch, so its sums are added
-    // to the frame once, with plain loads and stores, when its last path has terminated.
+    // Per-wave colour sums of the (at most two) chunks the wave has paths in flight for.  They
+    // are added to the frame once, when the chunk's last path has terminated: with plain loads
+    // and stores while a tile's samples are one chunk (its 64 pixels then belong to this wave
+    // alone during the launch), with atomics when the samples are split over several chunks.
     uint32_t *acc = acc_base + wave * (2 * 64 * 3);
     for (int i = lane; i < 2 * 64 * 3; i += 64)
         acc[i] = 0u;
@@ -190,6 +191,7 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
     int cur = 0;
     uint32_t s_total0 = 0u, s_total1 = 0u, s_done0 = 0u, s_done1 = 0u;
     int s_x0[2] = { 0, 0 }, s_y0[2] = { 0, 0 }, s_tw[2] = { 1, 1 }, s_npx[2] = { 1, 1 };
+    uint32_t s_smp[2] = { 0u, 0u }; // first sample of the chunk's segment
     bool queue_empty = (a.sample_count == 0u);
 
     // per-lane path state
@@ -224,14 +226,22 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                     queue_empty = true;
                     break;
                 }
-                const uint32_t t = a.tile_first + c * a.tile_stride;
+                uint32_t k = c, seg = 0u;
+                if (a.segments > 1u) {
+                    k = c / a.segments;
+                    seg = c - k * a.segments;
+                }
+                const uint32_t seg_first = seg * a.seg_samples;
+                const uint32_t seg_count = min(a.seg_samples, a.sample_count - seg_first);
+                const uint32_t t = a.tile_first + k * a.tile_stride;
                 const uint32_t ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
                 const int x0 = a.x0 + (int)tx * kTileW, y0 = a.y0 + (int)ty * kTileH;
                 const int tw = min(kTileW, a.x0 + a.w - x0), th = min(kTileH, a.y0 + a.h - y0);
                 cur = fs;
                 s_x0[fs] = x0; s_y0[fs] = y0; s_tw[fs] = tw; s_npx[fs] = tw * th;
+                s_smp[fs] = a.sample_begin + seg_first;
                 w_next = 0u;
-                w_end = (uint32_t)(tw * th) * a.sample_count;
+                w_end = (uint32_t)(tw * th) * seg_count;
                 if (fs == 0) { s_total0 = w_end; s_done0 = 0u; } else { s_total1 = w_end; s_done1 = 0u; }
             }
             const int ch_x0 = s_x0[cur], ch_y0 = s_y0[cur], ch_tw = s_tw[cur], ch_npx = s_npx[cur];
@@ -246,7 +256,7 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                 const int lx = (int)p - ly * ch_tw;
                 const int px = ch_x0 + lx, py = ch_y0 + ly;
                 pixel = (uint32_t)px + (uint32_t)py * a.width;
-                sample = a.sample_begin + s;
+                sample = s_smp[cur] + s;
                 acc_at = (uint32_t)cur * 192u + p * 3u;
                 call = 0u;
                 uint32_t w[4];
@@ -492,7 +502,10 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                         uint32_t *src = acc + sl * 192 + lane * 3;
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch) {
-                            dst[ch] += src[ch];
+                            if (a.segments > 1u)
+                                atomicAdd(dst + ch, src[ch]);
+                            else
+                                dst[ch] += src[ch];
                             src[ch] = 0u;
                         }
                     }

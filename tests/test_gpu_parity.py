@@ -312,6 +312,43 @@ def test_sample_slices_and_interleaved_tiles_are_partition_invariant(ctx, torch)
     assert np.array_equal(d_rgb.cpu().numpy().reshape(H, W, 3), want)
 
 
+@pytest.mark.parametrize("filt", [rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX, rtamd.FILTER_BVH])
+def test_split_sample_ranges_give_the_same_sums(ctx, torch, filt):
+    """A small frame's tiles are cut into sample segments (several waves then add into the same
+    pixels); the sums and the ray count are those of the unsplit run and of the oracle, for ragged
+    segments, sample slices and interleaved tile sets alike."""
+    sc = c3_scene()
+    ctx.set_scene(sc)
+    ctx.set_option(rtamd.OPT_FILTER, filt)
+    cam = rtamd.make_camera(*C3_CAM)
+    W, H, SPP, D = 61, 43, 37, 6  # ragged tiles at both edges, 37 = 4*9 + 1 samples
+    _, sums_o, rays_o = O.trace_tile(sc, O.camera(*C3_CAM), W, H, SPP, D, O.RNG_COUNTER, seed=21, want_sums=True)
+    d_sums = torch.zeros(H * W * 3, dtype=torch.int32, device="cuda")
+    try:
+        for per_wave in (0, 1, 16, 256):
+            ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, per_wave)
+            d_sums.zero_()
+            ctx.reset_stats()
+            ctx.accumulate_device(cam, rtamd.params(W, H, SPP, D, seed=21), d_sums.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(d_sums.cpu().numpy().view(np.uint32).reshape(H, W, 3), sums_o), per_wave
+            assert ctx.stats().rays == rays_o
+        # split segments within sample slices and interleaved tile sets
+        ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, 256)
+        d_sums.zero_()
+        ctx.reset_stats()
+        for s0, sc_ in ((0, 9), (9, 20), (29, 8)):
+            for first in range(2):
+                p = rtamd.params(W, H, SPP, D, seed=21, sample_begin=s0, sample_count=sc_, tile_first=first, tile_stride=2)
+                ctx.accumulate_device(cam, p, d_sums.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_sums.cpu().numpy().view(np.uint32).reshape(H, W, 3), sums_o)
+        assert ctx.stats().rays == rays_o
+    finally:
+        ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, 16)
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
+
+
 def test_edge_cases(ctx):
     cam = rtamd.default_camera()
     # empty scene: every ray is sky
