@@ -47,6 +47,7 @@ struct rt_context {
     int bvh_leaf_max = 4;
     uint32_t bvh_suspend_lanes = 16;  // see RT_OPT_BVH_SUSPEND_LANES
     uint32_t bvh_lds_nodes_max = 512; // trees up to this many nodes (64 B each) are walked in LDS
+    uint32_t subtiles_max = 4;     // work queue: tiles may be cut into this many rectangles (1, 2 or 4)
     uint32_t chunks_per_wave = 16; // work queue: split tiles' samples until there are this many chunks per resident wave
     uint32_t bvh_auto_min = 64;    // automatic choice: hierarchy from this many spheres up (measured crossover)
     float4 *d_bvh_nodes = nullptr;
@@ -309,23 +310,34 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     uint32_t n_wg = (uint32_t)ctx->n_cus * (uint32_t)per_cu;
     // A chunk is owned by one wave.  A call with few tiles per resident wave (a small frame, or
     // one rank's share of a frame) would leave waves idle or the last ones running alone, so its
-    // tiles' sample ranges are cut into segments of at least kMinSegment samples, each a chunk.
+    // tiles are cut into smaller chunks of at least 256 paths: first into halves or quadrants
+    // (disjoint pixels, plain stores), then the sample range into segments (atomic adds).
+    a.subtiles = 1u;
     a.segments = 1u;
     a.seg_samples = a.sample_count;
     {
         const uint64_t wanted = (uint64_t)ctx->chunks_per_wave * 4u * n_wg;
-        const uint32_t kMinSegment = 4u;
-        if (wanted > a.n_chunks && a.sample_count >= 2u * kMinSegment) {
-            const uint64_t s_wanted = (wanted + a.n_chunks - 1u) / a.n_chunks;
-            uint32_t per = (uint32_t)((a.sample_count + s_wanted - 1u) / s_wanted);
-            if (per < kMinSegment)
-                per = kMinSegment;
-            const uint32_t segs = (a.sample_count + per - 1u) / per; // every segment non-empty
-            if (segs > 1u && (uint64_t)a.n_chunks * segs <= 0x7fffffffull) {
-                a.segments = segs;
-                a.seg_samples = per;
-                a.n_chunks *= segs;
-            }
+        uint64_t per_tile = (wanted + a.n_chunks - 1u) / a.n_chunks; // chunks wanted of each tile
+        if (per_tile >= 2u && ctx->subtiles_max >= 2u && a.sample_count >= 8u)
+            a.subtiles = 2u;
+        if (per_tile >= 3u && ctx->subtiles_max >= 4u && a.sample_count >= 16u)
+            a.subtiles = 4u;
+        per_tile = (per_tile + a.subtiles - 1u) / a.subtiles;
+        const uint32_t min_segment = 4u * a.subtiles; // 256 paths on 64, 32 or 16 pixels
+        if (per_tile >= 2u && a.sample_count >= 2u * min_segment) {
+            uint32_t per = (uint32_t)((a.sample_count + per_tile - 1u) / per_tile);
+            if (per < min_segment)
+                per = min_segment;
+            a.segments = (a.sample_count + per - 1u) / per; // every segment non-empty
+            a.seg_samples = per;
+        }
+        const uint64_t total = (uint64_t)a.n_chunks * a.subtiles * a.segments;
+        if (total > 0x7fffffffull) {
+            a.subtiles = 1u;
+            a.segments = 1u;
+            a.seg_samples = a.sample_count;
+        } else {
+            a.n_chunks = (uint32_t)total;
         }
     }
     const uint32_t by_chunks = (a.n_chunks + 3u) / 4u;
@@ -865,6 +877,11 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
         if (value < 0 || value > 256)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_CHUNKS_PER_WAVE takes 0..256");
         ctx->chunks_per_wave = (uint32_t)value;
+        return RT_OK;
+    case RT_OPT_SUBTILES:
+        if (value != 1 && value != 2 && value != 4)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_SUBTILES takes 1, 2 or 4");
+        ctx->subtiles_max = (uint32_t)value;
         return RT_OK;
     case RT_OPT_BVH_MIN_SPHERES:
         if (value < 1 || value > (1ll << 30))

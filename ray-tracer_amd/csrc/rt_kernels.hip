@@ -226,22 +226,36 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                     queue_empty = true;
                     break;
                 }
-                uint32_t k = c, seg = 0u;
-                if (a.segments > 1u) {
-                    k = c / a.segments;
-                    seg = c - k * a.segments;
+                uint32_t k = c, sub = 0u, seg = 0u;
+                const uint32_t per_tile = a.subtiles * a.segments;
+                if (per_tile > 1u) {
+                    k = c / per_tile;
+                    const uint32_t r = c - k * per_tile;
+                    sub = r / a.segments;
+                    seg = r - sub * a.segments;
                 }
                 const uint32_t seg_first = seg * a.seg_samples;
                 const uint32_t seg_count = min(a.seg_samples, a.sample_count - seg_first);
                 const uint32_t t = a.tile_first + k * a.tile_stride;
                 const uint32_t ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-                const int x0 = a.x0 + (int)tx * kTileW, y0 = a.y0 + (int)ty * kTileH;
-                const int tw = min(kTileW, a.x0 + a.w - x0), th = min(kTileH, a.y0 + a.h - y0);
+                // the tile, clipped to the region, then the chunk's rectangle of it (possibly empty)
+                int x0 = a.x0 + (int)tx * kTileW, y0 = a.y0 + (int)ty * kTileH;
+                int tw = min(kTileW, a.x0 + a.w - x0), th = min(kTileH, a.y0 + a.h - y0);
+                if (a.subtiles == 2u) {
+                    y0 += (int)sub * (kTileH / 2);
+                    th = min(kTileH / 2, th - (int)sub * (kTileH / 2));
+                } else if (a.subtiles == 4u) {
+                    x0 += (int)(sub & 1u) * (kTileW / 2);
+                    tw = min(kTileW / 2, tw - (int)(sub & 1u) * (kTileW / 2));
+                    y0 += (int)(sub >> 1) * (kTileH / 2);
+                    th = min(kTileH / 2, th - (int)(sub >> 1) * (kTileH / 2));
+                }
+                const int npx = (tw > 0 && th > 0) ? tw * th : 0;
                 cur = fs;
-                s_x0[fs] = x0; s_y0[fs] = y0; s_tw[fs] = tw; s_npx[fs] = tw * th;
+                s_x0[fs] = x0; s_y0[fs] = y0; s_tw[fs] = max(tw, 1); s_npx[fs] = npx;
                 s_smp[fs] = a.sample_begin + seg_first;
                 w_next = 0u;
-                w_end = (uint32_t)(tw * th) * seg_count;
+                w_end = (uint32_t)npx * seg_count;
                 if (fs == 0) { s_total0 = w_end; s_done0 = 0u; } else { s_total1 = w_end; s_done1 = 0u; }
             }
             const int ch_x0 = s_x0[cur], ch_y0 = s_y0[cur], ch_tw = s_tw[cur], ch_npx = s_npx[cur];

@@ -21,6 +21,7 @@ MAT_GLASS, MAT_DIFFUSE, MAT_METAL, MAT_FUZZYMETAL = 0, 1, 2, 3
 OPT_FILTER, OPT_TILE_SPHERES, OPT_WORKGROUPS_PER_CU, OPT_BVH_LEAF_SPHERES, OPT_BVH_MIN_SPHERES, OPT_BVH_LDS_NODES = 0, 1, 2, 3, 4, 5
 OPT_BVH_SUSPEND_LANES = 6
 OPT_CHUNKS_PER_WAVE = 7
+OPT_SUBTILES = 8
 FILTER_AUTO, FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX, FILTER_BVH = -1, 0, 1, 2, 3
 
 # every symbol include/rt_mi355x.h declares

@@ -314,9 +314,9 @@ def test_sample_slices_and_interleaved_tiles_are_partition_invariant(ctx, torch)
 
 @pytest.mark.parametrize("filt", [rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX, rtamd.FILTER_BVH])
 def test_split_sample_ranges_give_the_same_sums(ctx, torch, filt):
-    """A small frame's tiles are cut into sample segments (several waves then add into the same
-    pixels); the sums and the ray count are those of the unsplit run and of the oracle, for ragged
-    segments, sample slices and interleaved tile sets alike."""
+    """A small frame's tiles are cut into halves or quadrants and into sample segments (several
+    waves then add into the same pixels); the sums and the ray count are those of the uncut run and
+    of the oracle, for ragged tiles and segments, sample slices and interleaved tile sets alike."""
     sc = c3_scene()
     ctx.set_scene(sc)
     ctx.set_option(rtamd.OPT_FILTER, filt)
@@ -325,13 +325,14 @@ def test_split_sample_ranges_give_the_same_sums(ctx, torch, filt):
     _, sums_o, rays_o = O.trace_tile(sc, O.camera(*C3_CAM), W, H, SPP, D, O.RNG_COUNTER, seed=21, want_sums=True)
     d_sums = torch.zeros(H * W * 3, dtype=torch.int32, device="cuda")
     try:
-        for per_wave in (0, 1, 16, 256):
+        for per_wave, subtiles in ((0, 4), (1, 1), (16, 1), (256, 1), (1, 2), (256, 2), (1, 4), (16, 4), (256, 4)):
             ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, per_wave)
+            ctx.set_option(rtamd.OPT_SUBTILES, subtiles)
             d_sums.zero_()
             ctx.reset_stats()
             ctx.accumulate_device(cam, rtamd.params(W, H, SPP, D, seed=21), d_sums.data_ptr())
             torch.cuda.synchronize()
-            assert np.array_equal(d_sums.cpu().numpy().view(np.uint32).reshape(H, W, 3), sums_o), per_wave
+            assert np.array_equal(d_sums.cpu().numpy().view(np.uint32).reshape(H, W, 3), sums_o), (per_wave, subtiles)
             assert ctx.stats().rays == rays_o
         # split segments within sample slices and interleaved tile sets
         ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, 256)
@@ -346,6 +347,7 @@ def test_split_sample_ranges_give_the_same_sums(ctx, torch, filt):
         assert ctx.stats().rays == rays_o
     finally:
         ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, 16)
+        ctx.set_option(rtamd.OPT_SUBTILES, 4)
         ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
 
 

@@ -13,7 +13,7 @@ SETS = (
     ("500 random spheres", scenes.random_spheres(500), rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA), 8,
      ((480, 270, 64), (960, 540, 64), (1920, 1080, 64), (1920, 1080, 8), (3840, 2160, 16))),
 )
-GRAN = tuple(int(v) for v in sys.argv[1:]) or (0, 4, 16, 64)
+GRAN = tuple(int(v) for v in sys.argv[1:]) or (0, 16, -16, -32)  # negative: tiles are not cut into rectangles
 for title, scene, cam, depth, frames in SETS:
     ctx.set_scene(scene)
     print(title, flush=True)
@@ -22,7 +22,8 @@ for title, scene, cam, depth, frames in SETS:
         p = rtamd.params(W, H, spp, depth, seed=1)
         line = f"  {W}x{H} {spp:4d} spp, {((W + 7) // 8) * ((H + 7) // 8):6d} tiles:"
         for g in GRAN:
-            ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, g)
+            ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, abs(g))
+            ctx.set_option(rtamd.OPT_SUBTILES, 1 if g < 0 else 4)
             best = 1e9
             for it in range(6):
                 ctx.reset_stats(); torch.cuda.synchronize(); t0 = time.time()
