@@ -208,10 +208,10 @@ typedef enum rt_option {
     RT_OPT_BVH_SUSPEND_LANES = 6, /* a 64-lane wave stops walking the hierarchy when at most this many of its rays
                                      are still at it; they resume in the wave's next pass (0..63, 0 = never) */
     RT_OPT_CHUNKS_PER_WAVE = 7,   /* work queue granularity: a call whose 8x8-pixel tiles number fewer than this many
-                                     per resident wave cuts each tile into halves or quadrants and then its samples
+                                     per resident wave cuts each tile into 2 or 4 strips of rows and then its samples
                                      into segments, chunks of at least 256 paths; segments add into the frame with
                                      atomics (0..256, default 16, 0 = never cut).  Results do not depend on it. */
-    RT_OPT_SUBTILES = 8           /* most rectangles a tile is cut into before its samples are: 1, 2 or 4 (default) */
+    RT_OPT_SUBTILES = 8           /* most strips of rows a tile is cut into before its samples are: 1, 2 or 4 (default) */
 } rt_option;
 
 int rt_set_option(rt_context *ctx, int option, int64_t value);

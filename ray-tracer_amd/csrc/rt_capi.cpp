@@ -47,7 +47,7 @@ struct rt_context {
     int bvh_leaf_max = 4;
     uint32_t bvh_suspend_lanes = 16;  // see RT_OPT_BVH_SUSPEND_LANES
     uint32_t bvh_lds_nodes_max = 512; // trees up to this many nodes (64 B each) are walked in LDS
-    uint32_t subtiles_max = 4;     // work queue: tiles may be cut into this many rectangles (1, 2 or 4)
+    uint32_t subtiles_max = 4;     // work queue: tiles may be cut into this many strips of rows (1, 2 or 4)
     uint32_t chunks_per_wave = 16; // work queue: split tiles' samples until there are this many chunks per resident wave
     uint32_t bvh_auto_min = 64;    // automatic choice: hierarchy from this many spheres up (measured crossover)
     float4 *d_bvh_nodes = nullptr;
@@ -310,7 +310,7 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     uint32_t n_wg = (uint32_t)ctx->n_cus * (uint32_t)per_cu;
     // A chunk is owned by one wave.  A call with few tiles per resident wave (a small frame, or
     // one rank's share of a frame) would leave waves idle or the last ones running alone, so its
-    // tiles are cut into smaller chunks of at least 256 paths: first into halves or quadrants
+    // tiles are cut into smaller chunks of at least 256 paths: first into 2 or 4 strips of rows
     // (disjoint pixels, plain stores), then the sample range into segments (atomic adds).
     a.subtiles = 1u;
     a.segments = 1u;

@@ -64,10 +64,10 @@ struct TraceArgs {
     int32_t x0, y0, w, h;      // traced region
     uint32_t tiles_x, tiles_y; // 8x8 tiles of the region
     uint32_t tile_first, tile_stride; // the call's tiles: tile_first + k*tile_stride
-    // Work queue: a tile is cut into `subtiles` rectangles (1: whole, 2: upper and lower 8x4 half,
-    // 4: 4x4 quadrants) and its sample range into `segments` runs of seg_samples samples (the last
-    // may be shorter, none is empty).  Chunk c is tile k = c / (subtiles*segments), rectangle
-    // (c / segments) % subtiles, segment c % segments.  A rectangle clipped away by the region's
+    // Work queue: a tile is cut into `subtiles` strips of 8/subtiles rows (1, 2 or 4; strips touch
+    // the same memory lines of `sums` as the whole tile) and its sample range into `segments` runs of seg_samples samples (the last
+    // may be shorter, none is empty).  Chunk c is tile k = c / (subtiles*segments), strip
+    // (c / segments) % subtiles, segment c % segments.  A strip clipped away by the region's
     // edge is an empty chunk.  With segments > 1 several waves add into the same pixels of `sums`.
     uint32_t n_chunks, subtiles, segments, seg_samples;
     uint32_t *sums;            // full frame uint32 x3

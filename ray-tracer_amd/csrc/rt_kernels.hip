@@ -238,17 +238,15 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                 const uint32_t seg_count = min(a.seg_samples, a.sample_count - seg_first);
                 const uint32_t t = a.tile_first + k * a.tile_stride;
                 const uint32_t ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-                // the tile, clipped to the region, then the chunk's rectangle of it (possibly empty)
-                int x0 = a.x0 + (int)tx * kTileW, y0 = a.y0 + (int)ty * kTileH;
-                int tw = min(kTileW, a.x0 + a.w - x0), th = min(kTileH, a.y0 + a.h - y0);
-                if (a.subtiles == 2u) {
-                    y0 += (int)sub * (kTileH / 2);
-                    th = min(kTileH / 2, th - (int)sub * (kTileH / 2));
-                } else if (a.subtiles == 4u) {
-                    x0 += (int)(sub & 1u) * (kTileW / 2);
-                    tw = min(kTileW / 2, tw - (int)(sub & 1u) * (kTileW / 2));
-                    y0 += (int)(sub >> 1) * (kTileH / 2);
-                    th = min(kTileH / 2, th - (int)(sub >> 1) * (kTileH / 2));
+                // the tile, clipped to the region, then the chunk's strip of it (possibly empty)
+                const int x0 = a.x0 + (int)tx * kTileW;
+                int y0 = a.y0 + (int)ty * kTileH;
+                const int tw = min(kTileW, a.x0 + a.w - x0);
+                int th = min(kTileH, a.y0 + a.h - y0);
+                if (a.subtiles > 1u) { // strips of whole tile rows: the same memory lines as the tile's
+                    const int rows = kTileH / (int)a.subtiles;
+                    y0 += (int)sub * rows;
+                    th = min(rows, th - (int)sub * rows);
                 }
                 const int npx = (tw > 0 && th > 0) ? tw * th : 0;
                 cur = fs;

@@ -314,7 +314,7 @@ def test_sample_slices_and_interleaved_tiles_are_partition_invariant(ctx, torch)
 
 @pytest.mark.parametrize("filt", [rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX, rtamd.FILTER_BVH])
 def test_split_sample_ranges_give_the_same_sums(ctx, torch, filt):
-    """A small frame's tiles are cut into halves or quadrants and into sample segments (several
+    """A small frame's tiles are cut into strips of rows and into sample segments (several
     waves then add into the same pixels); the sums and the ray count are those of the uncut run and
     of the oracle, for ragged tiles and segments, sample slices and interleaved tile sets alike."""
     sc = c3_scene()

@@ -13,7 +13,7 @@ SETS = (
     ("500 random spheres", scenes.random_spheres(500), rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA), 8,
      ((480, 270, 64), (960, 540, 64), (1920, 1080, 64), (1920, 1080, 8), (3840, 2160, 16))),
 )
-GRAN = tuple(int(v) for v in sys.argv[1:]) or (0, 16, -16, -32)  # negative: tiles are not cut into rectangles
+GRAN = tuple(int(v) for v in sys.argv[1:]) or (0, 16, -16, -32)  # negative: tiles are not cut into strips
 for title, scene, cam, depth, frames in SETS:
     ctx.set_scene(scene)
     print(title, flush=True)
