@@ -351,6 +351,43 @@ def test_split_sample_ranges_give_the_same_sums(ctx, torch, filt):
         ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
 
 
+def test_random_calls_do_not_depend_on_how_the_queue_cuts_them(ctx, torch):
+    """Random frame sizes, regions (some hanging over the frame), sample slices and interleaved tile
+    sets, each traced with whole-tile chunks and with random cuts: same sums, same ray count."""
+    rs = np.random.RandomState(2024)
+    cam = rtamd.make_camera(*C3_CAM)
+    try:
+        for case in range(48):
+            if case % 16 == 0:
+                ctx.set_scene(scenes.random_spheres(int(rs.choice([3, 40, 200, 700])), grid_half=int(rs.randint(3, 9)), seed=case))
+            W, H = int(rs.randint(1, 150)), int(rs.randint(1, 100))
+            spp = int(rs.choice([1, 3, 7, 8, 9, 16, 33, 64, 130]))
+            s0 = int(rs.randint(0, spp))
+            cnt = int(rs.randint(1, spp - s0 + 1))
+            stride = int(rs.choice([0, 0, 2, 5]))
+            first = int(rs.randint(0, stride)) if stride else 0
+            tile = None
+            if rs.rand() < 0.5:
+                tile = (int(rs.randint(-10, W)), int(rs.randint(-10, H)), int(rs.randint(1, W + 20)), int(rs.randint(1, H + 20)))
+            p = rtamd.params(W, H, spp, int(rs.randint(1, 9)), seed=case, sample_begin=s0, sample_count=cnt,
+                             tile_first=first, tile_stride=stride)
+            ctx.set_option(rtamd.OPT_FILTER, int(rs.choice([rtamd.FILTER_AUTO, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_BVH])))
+            out = []
+            for per_wave, subtiles in ((0, 4), (int(rs.choice([1, 16, 256])), int(rs.choice([1, 2, 4])))):
+                ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, per_wave)
+                ctx.set_option(rtamd.OPT_SUBTILES, subtiles)
+                d_sums = torch.full((H * W * 3,), 5, dtype=torch.int32, device="cuda")
+                ctx.reset_stats()
+                ctx.accumulate_device(cam, p, d_sums.data_ptr(), tile=tile)
+                torch.cuda.synchronize()
+                out.append((d_sums.cpu().numpy(), ctx.stats().rays))
+            assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1], (case, W, H, spp, s0, cnt, stride, first, tile)
+    finally:
+        ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, 16)
+        ctx.set_option(rtamd.OPT_SUBTILES, 4)
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
+
+
 def test_edge_cases(ctx):
     cam = rtamd.default_camera()
     # empty scene: every ray is sky
