@@ -231,7 +231,8 @@ def main():
                              "c5": "random-spheres scene, 10000 spheres, 1920x1080, 256 spp per frame, max depth 8 (BASELINE configs[4])"}[args.workload],
                 "spheres": N_SPHERES, "width": W, "height": H, "frame_spp": total_spp,
                 "max_depth": DEPTH, "partition": args.partition, "scan": scan,
-                "collective": "reduce(sum,int32,%d) to rank 0" % (W * H * 3) if world > 1 else "none",
+                "collective": ("none" if world == 1 else
+                               "reduce(sum,%s,%d) to rank 0" % ("uint8" if args.partition == "tiles" else "int32", W * H * 3)),
             },
             "rays_per_step": total_rays / args.steps,
             "lane_utilisation": total_rays / (64.0 * total_passes) if total_passes else None,

@@ -6,9 +6,11 @@ are integer sums, so a frame may be split either way and reassembled with one su
   "samples"  rank r traces samples [begin_r, begin_r + count_r) of every pixel;
   "tiles"    rank r traces all samples of the 8x8 tiles r, r + world, r + 2*world, ...
 
-Either way each rank adds into its own full-frame int32 sums tensor, the tensors are sum-reduced to
-rank 0 (the frame's only exchange step), and rank 0 divides by spp and packs RGB8 -- the frame is
-bit-identical to the single-GPU one.
+Either way each rank adds into its own full-frame int32 sums tensor and the frame has one exchange
+step.  Sample slices: the sums are sum-reduced to rank 0 (12 bytes per pixel), which divides by spp
+and packs RGB8.  Tiles: every pixel belongs to one rank with all its samples, so each rank resolves
+its own sums -- pixels of other ranks' tiles stay 0 -- and the RGB8 frames are sum-reduced to rank 0
+(3 bytes per pixel).  The frame is bit-identical to the single-GPU one.
 
 The tracer is duck-typed (`accumulate(params, sums)`, `resolve(sums, spp, rgb)`) so the CPU tests can
 drive this logic over gloo with a CPU tracer standing in for the device.
@@ -55,14 +57,20 @@ class DeviceTracer:
 
 
 def trace_frame(tracer, params, sums, rgb, rank, world, dist=None):
-    """One frame: zero, trace this rank's share, reduce to rank 0, resolve there.
+    """One frame: zero, trace this rank's share, exchange, and leave the RGB8 frame in rank 0's `rgb`.
 
     `params` is rank_params(...) (None = nothing to trace); `sums` an int32 tensor of width*height*3,
-    `rgb` a uint8 one (used on rank 0).  Enqueues only; the caller synchronises.
+    `rgb` a uint8 one (the frame on rank 0; scratch on the other ranks of a tile partition).
+    Enqueues only; the caller synchronises.
     """
     sums.zero_()
     if params is not None:
         tracer.accumulate(params, sums)
+    if world > 1 and params is not None and params.tile_stride > 1:
+        # interleaved tiles: disjoint pixels, so the resolved bytes can be exchanged instead of the sums
+        tracer.resolve(sums, params.width, params.height, params.spp, rgb)
+        dist.reduce(rgb, dst=0, op=dist.ReduceOp.SUM)
+        return
     if world > 1:
         dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
     if rank == 0:
