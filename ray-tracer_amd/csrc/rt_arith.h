@@ -127,11 +127,25 @@ __device__ __forceinline__ void ray_prepare(RayState &r)
 
 // Camera::GetRay, Source/main.cpp:440-444, for pixel (i, j) with jitter (ju, jv)
 // in [0,1): u and v are formed in double and narrowed (Source/main.cpp:627-628).
+// a / b correctly rounded, from rb = 1/b correctly rounded: q = a*rb is within one ulp of the
+// quotient, the residual a - b*q is then exact in one fused multiply-add, and a second one rounds
+// q + r*rb to the nearest double of a/b (Markstein's theorem; no overflow or underflow for the
+// frame coordinates this is used on).  Three full-rate instructions in place of a division sequence.
+__device__ __forceinline__ double divide_by_reciprocal(double a, double b, double rb)
+{
+    const double q = a * rb;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, rb, q);
+}
+
+// u, v of Source/main.cpp:627-628 (double sums and quotients, narrowed to float) and Camera::GetRay
+// (:440-444).  inv_width / inv_height are 1/(double)(float)width and height, rounded on the host.
 __device__ __forceinline__ void camera_ray(const rt_camera &cam, uint32_t width, uint32_t height,
+                                           double inv_width, double inv_height,
                                            int i, int j, double ju, double jv, RayState &r)
 {
-    const float u = (float)(((double)(float)i + ju) / (double)(float)width);
-    const float v = (float)(((double)(float)j + jv) / (double)(float)height);
+    const float u = (float)divide_by_reciprocal((double)(float)i + ju, (double)(float)width, inv_width);
+    const float v = (float)divide_by_reciprocal((double)(float)j + jv, (double)(float)height, inv_height);
     r.ox = cam.origin[0]; r.oy = cam.origin[1]; r.oz = cam.origin[2];
     r.dx = ((cam.bottom_left[0] + (cam.horizontal[0] * u)) + (v * cam.vertical[0])) - cam.origin[0];
     r.dy = ((cam.bottom_left[1] + (cam.horizontal[1] * u)) + (v * cam.vertical[1])) - cam.origin[1];

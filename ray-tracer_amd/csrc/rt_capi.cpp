@@ -258,6 +258,8 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     a.cam = *cam;
     a.width = p->width;
     a.height = p->height;
+    a.inv_width = 1.0 / (double)(float)p->width;
+    a.inv_height = 1.0 / (double)(float)p->height;
     a.sample_begin = p->sample_begin;
     a.sample_count = p->sample_count ? p->sample_count : p->spp;
     a.max_depth = p->max_depth;
@@ -749,6 +751,8 @@ int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width
     a.exact = ctx->d_geom_exact;
     a.n = ctx->n_spheres; a.cam = *cam;
     a.width = width; a.height = height; a.hits = d_hits;
+    a.inv_width = 1.0 / (double)(float)width;
+    a.inv_height = 1.0 / (double)(float)height;
     RT_HIP(ctx, launch_primary_hits(a, (hipStream_t)stream));
     return RT_OK;
 }

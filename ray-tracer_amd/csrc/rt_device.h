@@ -57,6 +57,7 @@ struct TraceArgs {
     BvhArgs bvh;               // kFilterBvh only
     rt_camera cam;
     uint32_t width, height;
+    double inv_width, inv_height; // 1/(double)(float)width, 1/(double)(float)height, correctly rounded
     uint32_t sample_begin, sample_count;
     int32_t max_depth;
     uint32_t flags;            // RT_FLAG_*
@@ -88,6 +89,7 @@ struct HitsArgs {
     uint32_t n;
     rt_camera cam;
     uint32_t width, height;
+    double inv_width, inv_height; // as in TraceArgs
     int32_t *hits;
     uint32_t use_bvh;          // walk `bvh` instead of scanning the list
     BvhArgs bvh;

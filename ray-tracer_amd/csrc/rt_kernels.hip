@@ -141,7 +141,7 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
 // ---------------------------------------------------------------------------
 
 template <bool MULTI_TILE, int FILTER, bool EXT>
-__global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs a)
+__global__ void __launch_bounds__(kTraceThreads, (FILTER == kFilterBvh && !EXT) ? 5 : 4) trace_kernel(const TraceArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     Geom *tile_f = reinterpret_cast<Geom *>(smem);
@@ -188,6 +188,9 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
 
     // wave-uniform queue state; slot s is free while s_total[s] == 0
     uint32_t w_next = 0u, w_end = 0u;
+    // item w_next of the current chunk is pixel w_pix of sample w_smp: w_next = w_smp * pixels + w_pix
+    uint32_t w_smp = 0u, w_pix = 0u;
+    float w_inv_npx = 1.0f, w_inv_tw = 1.0f; // reciprocals of the chunk's pixel count and width
     int cur = 0;
     uint32_t s_total0 = 0u, s_total1 = 0u, s_done0 = 0u, s_done1 = 0u;
     int s_x0[2] = { 0, 0 }, s_y0[2] = { 0, 0 }, s_tw[2] = { 1, 1 }, s_npx[2] = { 1, 1 };
@@ -253,6 +256,10 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
                 s_x0[fs] = x0; s_y0[fs] = y0; s_tw[fs] = max(tw, 1); s_npx[fs] = npx;
                 s_smp[fs] = a.sample_begin + seg_first;
                 w_next = 0u;
+                w_smp = 0u;
+                w_pix = 0u;
+                w_inv_npx = __builtin_amdgcn_rcpf((float)max(npx, 1));
+                w_inv_tw = __builtin_amdgcn_rcpf((float)max(tw, 1));
                 w_end = (uint32_t)npx * seg_count;
                 if (fs == 0) { s_total0 = w_end; s_done0 = 0u; } else { s_total1 = w_end; s_done1 = 0u; }
             }
@@ -261,26 +268,35 @@ __global__ void __launch_bounds__(kTraceThreads, 4) trace_kernel(const TraceArgs
             const uint32_t rank = lane_rank(need);
             const bool got = ((need >> lane) & 1ull) && rank < avail;
             if (got) {
-                const uint32_t item = w_next + rank;
-                const uint32_t s = item / (uint32_t)ch_npx;
-                const uint32_t p = item - s * (uint32_t)ch_npx;
-                const int ly = (int)(p / (uint32_t)ch_tw);
+                // Item w_next + rank is j = w_pix + rank pixels on from sample w_smp's first.  j / pixels
+                // and p / width as truncated float products: j < 128, pixels <= 64, so (j + 0.5) /
+                // pixels is at least 1/128 away from an integer, far more than the error of the
+                // reciprocal (within an ulp) and of the product.
+                const uint32_t j = w_pix + rank;
+                const uint32_t s = (uint32_t)(((float)j + 0.5f) * w_inv_npx);
+                const uint32_t p = j - __umul24(s, (uint32_t)ch_npx);
+                const int ly = (int)(uint32_t)(((float)p + 0.5f) * w_inv_tw);
                 const int lx = (int)p - ly * ch_tw;
                 const int px = ch_x0 + lx, py = ch_y0 + ly;
                 pixel = (uint32_t)px + (uint32_t)py * a.width;
-                sample = s_smp[cur] + s;
+                sample = s_smp[cur] + w_smp + s;
                 acc_at = (uint32_t)cur * 192u + p * 3u;
                 call = 0u;
                 uint32_t w[4];
                 philox4x32_10(pixel, sample, call++, a.key0, a.key1, w);
-                camera_ray(a.cam, a.width, a.height, px, py, (double)unit_float(w[0]),
+                camera_ray(a.cam, a.width, a.height, a.inv_width, a.inv_height, px, py, (double)unit_float(w[0]),
                            (double)unit_float(w[1]), ray);
                 depth = a.max_depth; // >= 1: the host does not launch for RAY_DEPTH <= 0
                 level = 0;
                 active = true;
             }
             const uint32_t want = (uint32_t)__popcll(need);
-            w_next += want < avail ? want : avail;
+            const uint32_t taken = want < avail ? want : avail; // <= 64
+            w_next += taken;
+            w_pix += taken; // < 128
+            const uint32_t whole = (uint32_t)(((float)w_pix + 0.5f) * w_inv_npx);
+            w_smp += whole;
+            w_pix -= __umul24(whole, (uint32_t)ch_npx);
             need &= ~__ballot(got);
         }
 
@@ -572,7 +588,7 @@ __global__ void __launch_bounds__(256) primary_hits_kernel(const HitsArgs a, uin
 
     RayState ray = {};
     if (inside)
-        camera_ray(a.cam, a.width, a.height, px, py, 0.5, 0.5, ray);
+        camera_ray(a.cam, a.width, a.height, a.inv_width, a.inv_height, px, py, 0.5, 0.5, ray);
 
     float closest = INFINITY;
     int best = -1;

@@ -55,7 +55,7 @@ def variant(n, s):
                       if (b2 == 12345678) w_sp = s2; }
                     bvh_begin(a.bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best);""")
     if n == 11:  # the camera ray of a new path is formed twice
-        return rep(s, "                depth = a.max_depth; // >= 1", """                { RayState r2; camera_ray(a.cam, a.width, a.height, px + 1, py, (double)unit_float(w[1]),
+        return rep(s, "                depth = a.max_depth; // >= 1", """                { RayState r2; camera_ray(a.cam, a.width, a.height, a.inv_width, a.inv_height, px + 1, py, (double)unit_float(w[1]),
                              (double)unit_float(w[0]), r2);
                   if (r2.four_a == 12345.0f) ray = r2; }
                 depth = a.max_depth; // >= 1""")
