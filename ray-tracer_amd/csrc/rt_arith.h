@@ -30,9 +30,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * (unsigned long long)c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        c0 = hi1 ^ c1 ^ k0;
+        // a ^ b ^ c as one three-input bit operation (truth table 0x96)
+        c0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
         c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1;
+        c2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
         c3 = lo0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
