@@ -346,7 +346,7 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     if (n_wg > by_chunks)
         n_wg = by_chunks;
 
-    RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk_counter, 0, sizeof(uint32_t), stream));
+    RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk_counter, 0, kQueues * kQueueStride * sizeof(uint32_t), stream));
     RT_HIP(ctx, launch_trace(a, n_wg, stream));
     return RT_OK;
 }
@@ -395,7 +395,7 @@ int rt_create(int device_id, rt_context **out)
     }
     ctx->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_chunk_counter, 256) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_chunk_counter, kQueues * kQueueStride * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_rays, 256) != hipSuccess ||
         hipMemset(ctx->d_rays, 0, 256) != hipSuccess) {
         rt_destroy(ctx);

@@ -11,6 +11,8 @@ namespace rtamd {
 
 // Threads per workgroup of the trace kernel: 4 waves, one per SIMD of a CU.
 constexpr int kTraceThreads = 256;
+constexpr uint32_t kQueues = 8;       // heads of the chunk queue (one address completes ~80 M atomics/s)
+constexpr uint32_t kQueueStride = 64; // words between heads: separate 256-byte blocks
 // Pixel tile one wave draws its samples from (also rt_params' tile unit).
 constexpr int kTileW = 8;
 constexpr int kTileH = 8;
@@ -73,7 +75,9 @@ struct TraceArgs {
     uint32_t n_chunks, subtiles, segments, seg_samples;
     uint32_t *sums;            // full frame uint32 x3
     unsigned long long *rays;  // [0] ray counter, [1] wave passes over the sphere list
-    uint32_t *chunk_counter;   // work queue head, zeroed before launch
+    // Work queue heads, zeroed before launch: kQueues counters kQueueStride words apart; queue q
+    // hands out chunks q, q + kQueues, q + 2 kQueues, ...
+    uint32_t *chunk_counter;
 };
 
 struct ResolveArgs {

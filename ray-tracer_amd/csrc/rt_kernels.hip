@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(kTraceThreads, (FILTER == kFilterBvh && !EXT) 
 
     // wave-uniform queue state; slot s is free while s_total[s] == 0
     uint32_t w_next = 0u, w_end = 0u;
+    uint32_t q_at = blockIdx.x % kQueues, q_left = kQueues; // queue in use, queues not yet found empty
     // item w_next of the current chunk is pixel w_pix of sample w_smp: w_next = w_smp * pixels + w_pix
     uint32_t w_smp = 0u, w_pix = 0u;
     float w_inv_npx = 1.0f, w_inv_tw = 1.0f; // reciprocals of the chunk's pixel count and width
@@ -221,10 +222,22 @@ __global__ void __launch_bounds__(kTraceThreads, (FILTER == kFilterBvh && !EXT) 
                 const int fs = s_total0 == 0u ? 0 : (s_total1 == 0u ? 1 : -1);
                 if (fs < 0)
                     break;
-                uint32_t c = 0u;
-                if (lane == 0)
-                    c = atomicAdd(a.chunk_counter, 1u);
-                c = __builtin_amdgcn_readfirstlane(c);
+                // The queue has kQueues heads: atomics on one address complete at about 80 million
+                // a second over the whole chip, which bounded calls with many small chunks.  A
+                // wave starts on its workgroup's queue and moves to the next when one runs dry.
+                uint32_t c = a.n_chunks;
+                while (q_left != 0u) {
+                    uint32_t k = 0u;
+                    if (lane == 0)
+                        k = atomicAdd(a.chunk_counter + q_at * kQueueStride, 1u);
+                    k = __builtin_amdgcn_readfirstlane(k);
+                    if (k < (a.n_chunks + (kQueues - 1u) - q_at) / kQueues) {
+                        c = k * kQueues + q_at;
+                        break;
+                    }
+                    q_at = (q_at + 1u) % kQueues;
+                    --q_left;
+                }
                 if (c >= a.n_chunks) {
                     queue_empty = true;
                     break;
