@@ -38,7 +38,9 @@ W, H, SPP, DEPTH, N_SPHERES = 1920, 1080, 64, 8, 500
 # Other BASELINE.json configurations, selectable with --workload (the default and the headline
 # number is "c3"): name -> (width, height, frame spp or None for 64 per GPU, spheres, grid, partition)
 WORKLOADS = {
-    "c3": (1920, 1080, None, 500, 11, "samples"),   # configs[2]; weak scaling: 64 spp per GPU
+    # configs[2]; weak scaling: 64 spp per GPU.  Sample slices: a rank's 1/N of the tiles at 64*N spp
+    # measured 0.26 ms slower at N = 8 (tools/share_time.py), about what its smaller exchange saves
+    "c3": (1920, 1080, None, 500, 11, "samples"),
     "c4": (3840, 2160, 1024, 500, 11, "samples"),   # configs[3]: 1024 spp split over the GPUs
     "c5": (1920, 1080, 256, 10000, 50, "tiles"),    # configs[4]: 10k spheres, tile-partitioned
 }
@@ -230,7 +232,7 @@ def main():
                              "c4": "random-spheres scene, 500 spheres, 3840x2160, 1024 spp per frame, max depth 8 (BASELINE configs[3])",
                              "c5": "random-spheres scene, 10000 spheres, 1920x1080, 256 spp per frame, max depth 8 (BASELINE configs[4])"}[args.workload],
                 "spheres": N_SPHERES, "width": W, "height": H, "frame_spp": total_spp,
-                "max_depth": DEPTH, "partition": args.partition, "scan": scan,
+                "max_depth": DEPTH, "partition": args.partition if world > 1 else "none (one GPU)", "scan": scan,
                 "collective": ("none" if world == 1 else
                                "reduce(sum,%s,%d) to rank 0" % ("uint8" if args.partition == "tiles" else "int32", W * H * 3)),
             },
