@@ -24,7 +24,9 @@
  *   - the reference calls its seam from four threads at once on disjoint tiles
  *     (Source/main.cpp:654): entry points taking a context lock it, so concurrent
  *     calls on one context are safe and run one after another (the _device entry
- *     points still only enqueue; rt_destroy must not race with anything).
+ *     points still only enqueue; rt_destroy must not race with anything).  Trace
+ *     launches of one context run one after another on the device as well, even
+ *     when they are enqueued on different streams (they share the work queue);
  */
 #ifndef RT_MI355X_H
 #define RT_MI355X_H

@@ -55,6 +55,10 @@ struct rt_context {
     uint32_t *d_bvh_index = nullptr;
 
     uint32_t *d_chunk_counter = nullptr;
+    // Trace launches of one context share the work queue's heads, so each waits for the one before
+    // it, whatever streams the caller passes: ev_trace is recorded behind every launch.
+    hipEvent_t ev_trace = nullptr;
+    bool trace_enqueued = false;
     unsigned long long *d_rays = nullptr;
 
     uint32_t *d_sums = nullptr; // scratch for rt_render*/rt_render_device
@@ -346,8 +350,12 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     if (n_wg > by_chunks)
         n_wg = by_chunks;
 
+    if (ctx->trace_enqueued)
+        RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_trace, 0));
     RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk_counter, 0, kQueues * kQueueStride * sizeof(uint32_t), stream));
     RT_HIP(ctx, launch_trace(a, n_wg, stream));
+    RT_HIP(ctx, hipEventRecord(ctx->ev_trace, stream));
+    ctx->trace_enqueued = true;
     return RT_OK;
 }
 
@@ -395,6 +403,7 @@ int rt_create(int device_id, rt_context **out)
     }
     ctx->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_trace, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&ctx->d_chunk_counter, kQueues * kQueueStride * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_rays, 256) != hipSuccess ||
         hipMemset(ctx->d_rays, 0, 256) != hipSuccess) {
@@ -420,6 +429,7 @@ int rt_destroy(rt_context *ctx)
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+    if (ctx->ev_trace) (void)hipEventDestroy(ctx->ev_trace);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;

@@ -283,6 +283,34 @@ def test_four_threads_call_the_seam_at_once_like_tracescene(ctx):
         assert np.array_equal(img, want)
 
 
+def test_launches_on_two_streams_of_one_context_do_not_disturb_each_other(ctx, torch):
+    """Trace launches share the context's work queue; enqueued back to back on different streams,
+    without any synchronisation by the caller, each must still trace every chunk exactly once."""
+    sc = c3_scene()
+    ctx.set_scene(sc)
+    cam = rtamd.make_camera(*C3_CAM)
+    W, H = 640, 360
+    pa, pb = rtamd.params(W, H, 16, 8, seed=5), rtamd.params(W, H, 3, 8, seed=6)
+    want = []
+    for p in (pa, pb):
+        d = torch.zeros(H * W * 3, dtype=torch.int32, device="cuda")
+        ctx.accumulate_device(cam, p, d.data_ptr())
+        torch.cuda.synchronize()
+        want.append(d.cpu().numpy())
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        da = torch.zeros(H * W * 3, dtype=torch.int32, device="cuda")
+        db = torch.zeros(H * W * 3, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.reset_stats()
+        ctx.accumulate_device(cam, pa, da.data_ptr(), stream=sa.cuda_stream)
+        ctx.accumulate_device(cam, pb, db.data_ptr(), stream=sb.cuda_stream)
+        ctx.accumulate_device(cam, pb, da.data_ptr(), stream=sb.cuda_stream)  # behind the first launch: same buffer
+        torch.cuda.synchronize()
+        assert np.array_equal(db.cpu().numpy(), want[1])
+        assert np.array_equal(da.cpu().numpy(), want[0] + want[1])
+
+
 def test_sample_slices_and_interleaved_tiles_are_partition_invariant(ctx, torch):
     sc = c3_scene()
     ctx.set_scene(sc)
