@@ -248,6 +248,23 @@ def main():
                 "kernel": "trace_kernel, %s scan" % scan,
             },
         }
+        # what the kernel executes, from the committed counter passes of the same command (profiles/)
+        ppath = os.path.join(ROOT, "profiles", "r01_last", "pmc_trace_kernel.json")
+        if os.path.exists(ppath) and args.workload == "c3":
+            try:
+                for name, rec in json.load(open(ppath)).items():
+                    if name.startswith(scan + " scan") and "derived" in rec:
+                        d = rec["derived"]
+                        line["roofline"]["executed"] = {
+                            "source": "profiles/r01_last/pmc_trace_kernel.json (rocprofv3 --pmc, separate passes)",
+                            "valu_instructions_per_launch": rec.get("SQ_INSTS_VALU"),
+                            "valu_instructions_per_cycle_per_simd": d.get("valu_instructions_per_cycle_per_simd"),
+                            "resident_waves_per_simd": d.get("resident_waves_per_simd"),
+                            "note": "wave64 VALU instructions issue every 2.3 or 4.7 cycles on this chip (measured), so "
+                                    "about 0.3 per cycle per SIMD is back-to-back issue for this mix",
+                        }
+            except Exception:
+                pass
         if scan == "hierarchy":
             line["roofline"]["note"] = ("algorithmic work = the reference's brute-force tests; the hierarchy skips most of "
                                         "them, so frac can exceed 1 -- see list_scan for the kernel that performs them all")
