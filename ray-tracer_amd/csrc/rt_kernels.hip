@@ -141,7 +141,7 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
 // ---------------------------------------------------------------------------
 
 template <bool MULTI_TILE, int FILTER, bool EXT>
-__global__ void __launch_bounds__(kTraceThreads, (FILTER == kFilterBvh && !EXT) ? 5 : 4) trace_kernel(const TraceArgs a)
+__global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) trace_kernel(const TraceArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     Geom *tile_f = reinterpret_cast<Geom *>(smem);
