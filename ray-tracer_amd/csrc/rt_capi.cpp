@@ -65,6 +65,14 @@ struct rt_context {
     size_t sums_bytes = 0;
     uint8_t *d_rgb = nullptr;   // scratch for rt_render
     size_t rgb_bytes = 0;
+    void *d_io_in = nullptr;    // scratch for rt_intersect's rays
+    size_t io_in_bytes = 0;
+    void *d_io_out = nullptr;   // scratch for rt_intersect's records and rt_primary_hits' map
+    size_t io_out_bytes = 0;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr; // device time of the synchronous calls' kernels
+    // resident workgroups per CU of the trace kernel, by (filter, LDS bytes): asked of the runtime once
+    struct OccEntry { int filter; size_t lds; int per_cu; };
+    std::vector<OccEntry> occupancy_cache;
 
     uint32_t tile_cap_max = 512;  // spheres per LDS tile (2 x 16 B each: 16 KiB; 4 workgroups per CU)
     int wg_per_cu_override = 0;
@@ -97,9 +105,50 @@ int fail_hip(rt_context *ctx, hipError_t e, const char *what)
             return fail_hip((ctx), e_, #call);             \
     } while (0)
 
+// Makes the context's device current for the duration of an entry point and gives the caller's
+// device back on every way out, so that a host driving several contexts (or its own HIP code)
+// never finds another device selected behind its back.
+class DeviceScope {
+public:
+    explicit DeviceScope(int device)
+    {
+        have_prev_ = hipGetDevice(&prev_) == hipSuccess;
+        status_ = (have_prev_ && prev_ == device) ? hipSuccess : hipSetDevice(device);
+        switched_ = status_ == hipSuccess && (!have_prev_ || prev_ != device);
+    }
+    ~DeviceScope()
+    {
+        if (switched_ && have_prev_)
+            (void)hipSetDevice(prev_);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+    hipError_t status() const { return status_; }
+
+private:
+    int prev_ = 0;
+    bool have_prev_ = false, switched_ = false;
+    hipError_t status_ = hipSuccess;
+};
+
+#define RT_DEVICE(ctx)                          \
+    DeviceScope device_scope_((ctx)->device);   \
+    RT_HIP((ctx), device_scope_.status())
+
 struct Region {
     int x0, y0, w, h;
 };
+
+// Preconditions of the conservative filters' error bounds and of the hierarchy builder: every
+// magnitude finite and below 2^28, r*r at least 2^-40.  Written as comparisons that are false
+// for NaN (fmax would drop a NaN operand).
+bool below_limit(float v) { return std::fabs(v) < 0x1p28f; }
+
+bool sphere_tame(const rt_sphere &sp, float rr)
+{
+    return below_limit(sp.center[0]) && below_limit(sp.center[1]) && below_limit(sp.center[2]) &&
+           below_limit(sp.radius) && rr >= 0x1p-40f;
+}
 
 // Clips TraceThreadFunction's tile to the frame: pixels outside it are dropped
 // by PutPixel in the reference (Source/main.cpp:275) and are not traced here.
@@ -126,6 +175,9 @@ int check_params(rt_context *ctx, const rt_camera *cam, const rt_params *p)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "width, height and spp must be positive");
     if ((uint64_t)p->width * p->height > (1ull << 30))
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "frame larger than 2^30 pixels");
+    // per-pixel sums are uint32 and a sample adds up to 255 per channel (Source/main.cpp:633-635)
+    if (p->spp > 0xFFFFFFFFu / 255u)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "spp above 16843009: the 32-bit colour sums could overflow");
     if (p->max_depth > 4096)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_depth above 4096");
     if (p->sample_count && (uint64_t)p->sample_begin + p->sample_count > p->spp)
@@ -216,8 +268,12 @@ int chosen_filter(const rt_context *ctx)
 }
 
 // Builds the hierarchy if need be and fills the kernels' view of it.
-int bvh_args(rt_context *ctx, BvhArgs &out)
+int bvh_args(rt_context *ctx, BvhArgs &out, bool may_build = true)
 {
+    if (!ctx->bvh_ready && !may_build)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT,
+                    "the hierarchy is not on the device yet and this entry point may not allocate it: "
+                    "set the options before rt_set_scene, or render once through another entry point");
     const int st = ensure_bvh(ctx);
     if (st != RT_OK)
         return st;
@@ -237,9 +293,12 @@ int bvh_args(rt_context *ctx, BvhArgs &out)
     return RT_OK;
 }
 
-// Enqueues the sample loop for `region` into d_sums.
+// Enqueues the sample loop for `region` into d_sums.  `queue_heads` = the work queue to use (null:
+// the context's own); with `may_allocate` false nothing is allocated on the way (the hierarchy
+// must be on the device already).
 int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p, const Region &rg,
-                       uint32_t *d_sums, hipStream_t stream)
+                       uint32_t *d_sums, hipStream_t stream, uint32_t *queue_heads = nullptr,
+                       bool may_allocate = true)
 {
     if (rg.w == 0 || rg.h == 0)
         return RT_OK;
@@ -250,7 +309,7 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     memset(&a, 0, sizeof a);
     a.filter = chosen_filter(ctx);
     if (a.filter == kFilterBvh) {
-        const int st = bvh_args(ctx, a.bvh);
+        const int st = bvh_args(ctx, a.bvh, may_allocate);
         if (st != RT_OK)
             return st;
     }
@@ -285,7 +344,7 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
         return RT_OK;
     a.sums = d_sums;
     a.rays = ctx->d_rays;
-    a.chunk_counter = ctx->d_chunk_counter;
+    a.chunk_counter = queue_heads ? queue_heads : ctx->d_chunk_counter;
 
     // LDS tile: the whole (padded) list when it fits, else tiles of tile_cap_max
     const uint32_t n_pad = (a.n + (kPad - 1)) & ~(uint32_t)(kPad - 1);
@@ -306,7 +365,14 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     if (lds > 160u * 1024u)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_depth too large: the bounce stack does not fit in LDS");
     int per_cu = 0;
-    RT_HIP(ctx, trace_occupancy(a.filter, lds, &per_cu));
+    for (const rt_context::OccEntry &e : ctx->occupancy_cache)
+        if (e.filter == a.filter && e.lds == lds)
+            per_cu = e.per_cu;
+    if (per_cu == 0) {
+        RT_HIP(ctx, trace_occupancy(a.filter, lds, &per_cu));
+        if (ctx->occupancy_cache.size() < 64u)
+            ctx->occupancy_cache.push_back({ a.filter, lds, per_cu });
+    }
     if (per_cu < 1)
         return fail(ctx, RT_ERR_HIP, "trace kernel does not fit on a CU");
     if (ctx->wg_per_cu_override > 0 && ctx->wg_per_cu_override < per_cu)
@@ -352,7 +418,7 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
 
     if (ctx->trace_enqueued)
         RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_trace, 0));
-    RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk_counter, 0, kQueues * kQueueStride * sizeof(uint32_t), stream));
+    RT_HIP(ctx, hipMemsetAsync(a.chunk_counter, 0, kQueues * kQueueStride * sizeof(uint32_t), stream));
     RT_HIP(ctx, launch_trace(a, n_wg, stream));
     RT_HIP(ctx, hipEventRecord(ctx->ev_trace, stream));
     ctx->trace_enqueued = true;
@@ -397,13 +463,15 @@ int rt_create(int device_id, rt_context **out)
         return RT_ERR_OUT_OF_MEMORY;
     ctx->device = device_id;
     hipDeviceProp_t prop;
-    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
+    DeviceScope scope(device_id);
+    if (scope.status() != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
         delete ctx;
         return RT_ERR_NO_DEVICE;
     }
     ctx->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_trace, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&ctx->ev_t0) != hipSuccess || hipEventCreate(&ctx->ev_t1) != hipSuccess ||
         hipMalloc((void **)&ctx->d_chunk_counter, kQueues * kQueueStride * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_rays, 256) != hipSuccess ||
         hipMemset(ctx->d_rays, 0, 256) != hipSuccess) {
@@ -418,7 +486,7 @@ int rt_destroy(rt_context *ctx)
 {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
-    (void)hipSetDevice(ctx->device);
+    DeviceScope scope(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->d_geom_exact) (void)hipFree(ctx->d_geom_exact);
     if (ctx->d_geom_filter) (void)hipFree(ctx->d_geom_filter);
@@ -429,7 +497,11 @@ int rt_destroy(rt_context *ctx)
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+    if (ctx->d_io_in) (void)hipFree(ctx->d_io_in);
+    if (ctx->d_io_out) (void)hipFree(ctx->d_io_out);
     if (ctx->ev_trace) (void)hipEventDestroy(ctx->ev_trace);
+    if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
+    if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -444,7 +516,7 @@ int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null sphere list");
     if (n > (1u << 24))
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "more than 2^24 spheres");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_DEVICE(ctx);
     RT_HIP(ctx, hipDeviceSynchronize());
     if (ctx->d_geom_exact) { RT_HIP(ctx, hipFree(ctx->d_geom_exact)); ctx->d_geom_exact = nullptr; }
     if (ctx->d_geom_filter) { RT_HIP(ctx, hipFree(ctx->d_geom_filter)); ctx->d_geom_filter = nullptr; }
@@ -496,10 +568,7 @@ int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n)
         matr[i].r2 = (float)(cc * (1.0 - 0x1p-18) - (double)r2w);
         // preconditions of the filters' error bounds: magnitudes below 2^28 (also after the
         // shift), r*r at least 2^-40
-        const float m = std::fmax(std::fmax(std::fmax(std::fabs(sp.center[0]), std::fabs(sp.center[1])),
-                                            std::fmax(std::fabs(sp.center[2]), std::fabs(sp.radius))),
-                                  std::fmax(std::fmax(std::fabs((float)cx), std::fabs((float)cy)), std::fabs((float)cz)));
-        if (!(m < 0x1p28f) || !(rr >= 0x1p-40f))
+        if (!sphere_tame(sp, rr) || !below_limit(cx) || !below_limit(cy) || !below_limit(cz))
             tame = false;
     }
     if (hipMalloc((void **)&ctx->d_geom_exact, cnt * sizeof(Geom)) != hipSuccess ||
@@ -518,6 +587,9 @@ int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n)
     ctx->scene_tame = tame;
     ctx->n_spheres = n;
     ctx->have_scene = true;
+    // the hierarchy, if the current options select it, goes to the device with the scene
+    if (chosen_filter(ctx) == kFilterBvh)
+        return ensure_bvh(ctx);
     return RT_OK;
 }
 
@@ -574,7 +646,7 @@ int rt_accumulate_device(rt_context *ctx, const rt_camera *cam, const rt_params 
         return st;
     if (!d_sums)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null d_sums");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_DEVICE(ctx);
     const Region rg = clip_region(*params, xstart, ystart, xsize, ysize);
     return enqueue_accumulate(ctx, cam, params, rg, d_sums, (hipStream_t)stream);
 }
@@ -588,7 +660,11 @@ int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, u
     std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     if (!d_sums || !d_rgb || width == 0 || height == 0 || spp_div == 0)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad resolve arguments");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if ((uint64_t)width * height > (1ull << 30))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "frame larger than 2^30 pixels");
+    if ((flags & ~(uint32_t)RT_FLAG_GAMMA2) != 0u)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_resolve_device takes RT_FLAG_GAMMA2 only");
+    RT_DEVICE(ctx);
     rt_params p;
     memset(&p, 0, sizeof p);
     p.width = width; p.height = height;
@@ -601,8 +677,10 @@ int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, u
     return RT_OK;
 }
 
-int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
-                     int ystart, int xsize, int ysize, uint8_t *d_rgb, void *stream)
+// rt_render_device and rt_render_device_static: the same sequence, the sums and the queue heads
+// either in the context's own buffers (grown as needed) or in the library's static array.
+static int render_device(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
+                         int ystart, int xsize, int ysize, uint8_t *d_rgb, void *stream, bool use_static)
 {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
@@ -612,28 +690,48 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *par
         return st;
     if (!d_rgb)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null d_rgb");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_DEVICE(ctx);
     hipStream_t s = (hipStream_t)stream;
-    const size_t sums_bytes = (size_t)params->width * params->height * 3u * sizeof(uint32_t);
-    st = ensure(ctx, (void **)&ctx->d_sums, &ctx->sums_bytes, sums_bytes);
-    if (st != RT_OK)
-        return st;
+    uint32_t *sums = nullptr, *queue_heads = nullptr;
+    if (use_static) {
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "no static scratch");
+    } else {
+        const size_t sums_bytes = (size_t)params->width * params->height * 3u * sizeof(uint32_t);
+        st = ensure(ctx, (void **)&ctx->d_sums, &ctx->sums_bytes, sums_bytes);
+        if (st != RT_OK)
+            return st;
+        sums = ctx->d_sums;
+    }
     const Region rg = clip_region(*params, xstart, ystart, xsize, ysize);
     if (rg.w == 0 || rg.h == 0)
         return RT_OK;
-    // zero the rows of the region, trace, divide
+    // Zero the rows of the region, trace, divide.  The sums are the context's own scratch and
+    // calls may come on different streams (the reference's four strips share every row), so the
+    // whole sequence is ordered behind the previous user of the scratch: ev_trace is waited for
+    // before the memset and recorded again behind the resolve.
+    if (ctx->trace_enqueued)
+        RT_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_trace, 0));
     const size_t row_bytes = (size_t)params->width * 3u * sizeof(uint32_t);
-    RT_HIP(ctx, hipMemsetAsync((uint8_t *)ctx->d_sums + (size_t)rg.y0 * row_bytes, 0, (size_t)rg.h * row_bytes, s));
-    st = enqueue_accumulate(ctx, cam, params, rg, ctx->d_sums, s);
+    RT_HIP(ctx, hipMemsetAsync((uint8_t *)sums + (size_t)rg.y0 * row_bytes, 0, (size_t)rg.h * row_bytes, s));
+    st = enqueue_accumulate(ctx, cam, params, rg, sums, s, queue_heads, !use_static);
     if (st != RT_OK)
         return st;
     ResolveArgs a;
-    a.sums = ctx->d_sums; a.rgb = d_rgb;
+    a.sums = sums; a.rgb = d_rgb;
     a.width = params->width; a.height = params->height; a.spp_div = params->spp; a.flags = params->flags;
     a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
     RT_HIP(ctx, launch_resolve(a, s));
+    RT_HIP(ctx, hipEventRecord(ctx->ev_trace, s));
+    ctx->trace_enqueued = true;
     return RT_OK;
 }
+
+int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
+                     int ystart, int xsize, int ysize, uint8_t *d_rgb, void *stream)
+{
+    return render_device(ctx, cam, params, xstart, ystart, xsize, ysize, d_rgb, stream, false);
+}
+
 
 int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart, int ystart,
               int xsize, int ysize, uint8_t *rgb)
@@ -646,7 +744,7 @@ int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, in
         return st;
     if (!rgb)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null rgb");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_DEVICE(ctx);
     const auto t0 = std::chrono::steady_clock::now();
     const size_t frame_bytes = (size_t)params->width * params->height * 3u;
     st = ensure(ctx, (void **)&ctx->d_rgb, &ctx->rgb_bytes, frame_bytes);
@@ -656,9 +754,7 @@ int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, in
     if (rg.w == 0 || rg.h == 0)
         return RT_OK;
 
-    hipEvent_t e0, e1;
-    RT_HIP(ctx, hipEventCreate(&e0));
-    RT_HIP(ctx, hipEventCreate(&e1));
+    const hipEvent_t e0 = ctx->ev_t0, e1 = ctx->ev_t1;
     RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
     st = rt_render_device(ctx, cam, params, xstart, ystart, xsize, ysize, ctx->d_rgb, ctx->stream);
     if (st == RT_OK) {
@@ -678,8 +774,6 @@ int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, in
             st = fail_hip(ctx, e, "rt_render copy-back");
         }
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;
 }
@@ -698,7 +792,7 @@ int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null rgb or zero samples_per_pass");
     if (params->sample_count != 0 || params->sample_begin != 0)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "progressive render takes the whole sample range");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_DEVICE(ctx);
     const auto t0 = std::chrono::steady_clock::now();
     const size_t frame_bytes = (size_t)params->width * params->height * 3u;
     st = ensure(ctx, (void **)&ctx->d_rgb, &ctx->rgb_bytes, frame_bytes);
@@ -710,6 +804,8 @@ int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params
     if (rg.w == 0 || rg.h == 0)
         return RT_OK;
     hipStream_t s = ctx->stream;
+    if (ctx->trace_enqueued) // the sums are shared scratch: behind their previous user, as in rt_render_device
+        RT_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_trace, 0));
     const size_t row_bytes = (size_t)params->width * 3u * sizeof(uint32_t);
     RT_HIP(ctx, hipMemsetAsync((uint8_t *)ctx->d_sums + (size_t)rg.y0 * row_bytes, 0, (size_t)rg.h * row_bytes, s));
     const size_t pitch = (size_t)params->width * 3u;
@@ -727,6 +823,7 @@ int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params
         a.width = params->width; a.height = params->height; a.spp_div = done; a.flags = params->flags;
         a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
         RT_HIP(ctx, launch_resolve(a, s));
+        RT_HIP(ctx, hipEventRecord(ctx->ev_trace, s));
         RT_HIP(ctx, hipMemcpy2DAsync(rgb + off, pitch, ctx->d_rgb + off, pitch, (size_t)rg.w * 3u, (size_t)rg.h,
                                      hipMemcpyDeviceToHost, s));
         RT_HIP(ctx, hipStreamSynchronize(s));
@@ -747,7 +844,7 @@ int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad primary-hit arguments");
     if (!ctx->have_scene)
         return fail(ctx, RT_ERR_NO_SCENE, "rt_set_scene has not been called");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_DEVICE(ctx);
     HitsArgs a;
     memset(&a, 0, sizeof a);
     if (chosen_filter(ctx) == kFilterBvh) {
@@ -774,15 +871,18 @@ int rt_primary_hits(rt_context *ctx, const rt_camera *cam, uint32_t width, uint3
     std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     if (!hits)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null hits");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_DEVICE(ctx);
     const auto t0 = std::chrono::steady_clock::now();
     const size_t bytes = (size_t)width * height * sizeof(int32_t);
-    int32_t *d = nullptr;
     if (bytes == 0)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "empty frame");
-    if (hipMalloc((void **)&d, bytes) != hipSuccess)
-        return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for the hit map");
-    int st = rt_primary_hits_device(ctx, cam, width, height, d, ctx->stream);
+    if ((uint64_t)width * height > (1ull << 30))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "frame larger than 2^30 pixels");
+    int st = ensure(ctx, &ctx->d_io_out, &ctx->io_out_bytes, bytes); // kept for the next call
+    if (st != RT_OK)
+        return st;
+    int32_t *d = (int32_t *)ctx->d_io_out;
+    st = rt_primary_hits_device(ctx, cam, width, height, d, ctx->stream);
     if (st == RT_OK) {
         hipError_t e = hipMemcpyAsync(hits, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess)
@@ -790,7 +890,6 @@ int rt_primary_hits(rt_context *ctx, const rt_camera *cam, uint32_t width, uint3
         if (e != hipSuccess)
             st = fail_hip(ctx, e, "rt_primary_hits copy-back");
     }
-    (void)hipFree(d);
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;
 }
@@ -806,15 +905,15 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out)
         return RT_OK;
     if (!rays || !out)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null rays or out");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
-    float *d_rays = nullptr;
-    uint8_t *d_out = nullptr;
+    RT_DEVICE(ctx);
     const size_t in_bytes = (size_t)n * 6u * sizeof(float), out_bytes = (size_t)n * 32u;
-    if (hipMalloc((void **)&d_rays, in_bytes) != hipSuccess || hipMalloc((void **)&d_out, out_bytes) != hipSuccess) {
-        if (d_rays) (void)hipFree(d_rays);
-        return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for rt_intersect");
-    }
-    int st = RT_OK;
+    int st = ensure(ctx, &ctx->d_io_in, &ctx->io_in_bytes, in_bytes); // both kept for the next call
+    if (st == RT_OK)
+        st = ensure(ctx, &ctx->d_io_out, &ctx->io_out_bytes, out_bytes);
+    if (st != RT_OK)
+        return st;
+    float *d_rays = (float *)ctx->d_io_in;
+    uint8_t *d_out = (uint8_t *)ctx->d_io_out;
     hipError_t e = hipMemcpyAsync(d_rays, rays, in_bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         IntersectArgs a;
@@ -837,8 +936,6 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out)
         e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess && st == RT_OK)
         st = fail_hip(ctx, e, "rt_intersect");
-    (void)hipFree(d_rays);
-    (void)hipFree(d_out);
     return st;
 }
 
@@ -853,10 +950,10 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
         else if (value == 1) ctx->filter = kFilterConservative;
         else if (value == 2) ctx->filter = kFilterMatrix;
         else if (value == 3) ctx->filter = kFilterBvh;
-        else if (value == -1) { ctx->filter = kFilterMatrix; ctx->filter_forced = false; return RT_OK; }
+        else if (value == -1) { ctx->filter = kFilterMatrix; ctx->filter_forced = false; break; }
         else return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_FILTER takes -1, 0, 1, 2 or 3");
         ctx->filter_forced = true;
-        return RT_OK;
+        break;
     case RT_OPT_TILE_SPHERES:
         if (value < kPad || value > 4096)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_TILE_SPHERES takes 128..4096");
@@ -871,12 +968,12 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
         if (value < 1 || value > kBvhLeafMax)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_LEAF_SPHERES takes 1..15");
         if (ctx->bvh_leaf_max != (int)value) {
-            RT_HIP(ctx, hipSetDevice(ctx->device));
+            RT_DEVICE(ctx);
             RT_HIP(ctx, hipDeviceSynchronize());
             drop_bvh(ctx);
             ctx->bvh_leaf_max = (int)value;
         }
-        return RT_OK;
+        break;
     case RT_OPT_BVH_LDS_NODES:
         if (value < 0 || value > 2048)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_LDS_NODES takes 0..2048");
@@ -901,19 +998,30 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
         if (value < 1 || value > (1ll << 30))
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_MIN_SPHERES takes 1..2^30");
         ctx->bvh_auto_min = (uint32_t)value;
-        return RT_OK;
+        break;
     default:
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option");
     }
+    // an option that selects the hierarchy, or changes its shape, puts it on the device right away
+    if (ctx->have_scene && chosen_filter(ctx) == kFilterBvh && !ctx->bvh_ready) {
+        RT_DEVICE(ctx);
+        return ensure_bvh(ctx);
+    }
+    return RT_OK;
 }
 
 int rt_accel_selfcheck(const rt_sphere *spheres, uint32_t n, int leaf_spheres, uint32_t info[4])
 {
-    if ((n && !spheres) || leaf_spheres < 1 || leaf_spheres > kBvhLeafMax)
+    if ((n && !spheres) || leaf_spheres < 1 || leaf_spheres > kBvhLeafMax || n > (1u << 24))
         return RT_ERR_INVALID_ARGUMENT;
     std::vector<Geom> exact(n);
     for (uint32_t i = 0; i < n; ++i) {
         volatile float rr = spheres[i].radius * spheres[i].radius;
+        // The builder sorts and bins by coordinates: it is only defined for the scenes that
+        // rt_set_scene gives to it (finite, magnitudes below 2^28, r*r at least 2^-40); others
+        // are scanned without a hierarchy and are refused here.
+        if (!sphere_tame(spheres[i], rr))
+            return RT_ERR_INVALID_ARGUMENT;
         exact[i].cx = spheres[i].center[0];
         exact[i].cy = spheres[i].center[1];
         exact[i].cz = spheres[i].center[2];
@@ -937,7 +1045,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *stats)
     std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     if (!stats)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null stats");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_DEVICE(ctx);
     RT_HIP(ctx, hipDeviceSynchronize());
     unsigned long long counters[2] = { 0, 0 };
     RT_HIP(ctx, hipMemcpy(counters, ctx->d_rays, sizeof counters, hipMemcpyDeviceToHost));
@@ -954,7 +1062,7 @@ int rt_reset_stats(rt_context *ctx)
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_DEVICE(ctx);
     RT_HIP(ctx, hipDeviceSynchronize());
     RT_HIP(ctx, hipMemset(ctx->d_rays, 0, 2 * sizeof(unsigned long long)));
     ctx->last_kernel_ms = ctx->last_wall_ms = 0.0;

@@ -64,3 +64,18 @@ def test_degenerate_inputs_keep_depth_bounded():
 def test_bad_arguments():
     assert rtamd.accel_selfcheck(rtamd.default_scene(), 0)[0] != 0
     assert rtamd.accel_selfcheck(rtamd.default_scene(), 16)[0] != 0
+
+
+@pytest.mark.parametrize("field,value", [("center", np.nan), ("center", np.inf), ("center", -np.inf), ("center", 1e12),
+                                         ("radius", np.nan), ("radius", np.inf), ("radius", 0.0), ("radius", 1e-25)])
+def test_spheres_outside_the_builders_domain_are_refused(field, value):
+    """The builder sorts and bins by coordinates; NaN, Inf, huge magnitudes and zero radii are what
+    rt_set_scene never hands to it (such scenes take the exact list scan), so the host-only entry
+    point must refuse them instead of building on them."""
+    sc = scenes.random_spheres(200, grid_half=7)
+    if field == "center":
+        sc["center"][17, 1] = value
+    else:
+        sc["radius"][17] = value
+    st = rtamd.accel_selfcheck(sc, 4)[0]
+    assert st == -1

@@ -311,6 +311,49 @@ def test_launches_on_two_streams_of_one_context_do_not_disturb_each_other(ctx, t
         assert np.array_equal(da.cpu().numpy(), want[0] + want[1])
 
 
+def test_render_device_strips_on_four_streams_share_the_contexts_scratch(ctx, torch):
+    """TraceScene's four column strips (Source/main.cpp:647-659) through rt_render_device on four
+    streams, nothing synchronised by the caller: the strips share every row of the context's scratch
+    sums, so each call's zeroing, tracing and dividing must stay behind the previous call's."""
+    sc = c3_scene()
+    ctx.set_scene(sc)
+    cam = rtamd.make_camera(*C3_CAM)
+    W, H = 512, 288
+    p = rtamd.params(W, H, 12, 8, seed=17)
+    want = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+    ctx.render_device(cam, p, want.data_ptr())
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    for _ in range(4):
+        got = torch.full((H * W * 3,), 255, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for i, s in enumerate(streams):
+            ctx.render_device(cam, p, got.data_ptr(), tile=(i * (W // 4), 0, W // 4, H), stream=s.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+
+
+def test_scene_with_nan_and_infinite_spheres_takes_the_exact_scan(ctx):
+    """NaN or infinite centres and radii put a scene outside the filters' and the hierarchy's
+    preconditions; it must be scanned the reference's way, whatever scan is asked for."""
+    sc = scenes.random_spheres(120, grid_half=5, seed=9)
+    sc["center"][11, 0] = np.nan
+    sc["center"][12, 2] = np.inf
+    sc["radius"][13] = np.nan
+    sc["radius"][14] = np.inf
+    want, _, rays = O.trace_tile(sc, O.camera(*C3_CAM), 64, 36, 3, 6, O.RNG_COUNTER, seed=2)
+    try:
+        for filt in (rtamd.FILTER_AUTO, rtamd.FILTER_MATRIX, rtamd.FILTER_BVH):
+            ctx.set_option(rtamd.OPT_FILTER, filt)
+            ctx.set_scene(sc)
+            ctx.reset_stats()
+            got = ctx.render(rtamd.make_camera(*C3_CAM), rtamd.params(64, 36, 3, 6, seed=2))
+            assert np.array_equal(got, want), filt
+            assert ctx.stats().rays == rays
+    finally:
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
+
+
 def test_sample_slices_and_interleaved_tiles_are_partition_invariant(ctx, torch):
     sc = c3_scene()
     ctx.set_scene(sc)
@@ -474,6 +517,8 @@ def test_error_paths(ctx):
     bad = rtamd.params(8, 8, 4, 1, sample_begin=3, sample_count=2)
     assert fresh.call("rt_render", C.byref(cam), C.byref(bad), 0, 0, 8, 8, buf.ctypes.data) == -1
     assert b"sample range" in rtamd.load().rt_last_error(fresh._h)
+    bad = rtamd.params(8, 8, 16843010, 1)  # 255 * spp would not fit the 32-bit sums
+    assert fresh.call("rt_render", C.byref(cam), C.byref(bad), 0, 0, 8, 8, buf.ctypes.data) == -1
     assert fresh.call("rt_set_option", 99, 0) == -1
     fresh.close()
 
