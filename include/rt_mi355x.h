@@ -162,6 +162,21 @@ int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params
 int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
                      int ystart, int xsize, int ysize, uint8_t *d_rgb, void *stream);
 
+/* rt_render_device for callers that cannot allocate.  It has no counterpart in the reference; it
+ * is for code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.
+ * Same arguments, same result, but the per-pixel colour sums and the work queue's heads live in a
+ * file-scope device array of the library instead of buffers the context grows on demand, and the
+ * call allocates and frees nothing (no hipMalloc, no hipFree).  Limits and rules:
+ *   - width * height <= RT_STATIC_MAX_PIXELS, else RT_ERR_INVALID_ARGUMENT;
+ *   - each GPU the library runs on holds its own copy of the array (24 MiB + 2 KiB) until the
+ *     process ends, and ALL contexts on one GPU share it: calls that overlap in time on one GPU race
+ *     (calls on one context are ordered by the library, whatever their streams);
+ *   - the scan's device data must exist already: rt_set_scene and rt_set_option put the hierarchy
+ *     on the device when the options select it, so this holds unless an earlier error prevented it. */
+#define RT_STATIC_MAX_PIXELS (1u << 21) /* 2 097 152: 1920 x 1080 fits */
+int rt_render_device_static(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
+                            int ystart, int xsize, int ysize, uint8_t *d_rgb, void *stream);
+
 /* The sample loop of Source/main.cpp:623-636 for samples [sample_begin,
  * sample_begin+sample_count) and the tiles selected by tile_first/tile_stride:
  * ADDS each sample's byte colour into `d_sums` (full frame, width*height*3

@@ -55,6 +55,9 @@ struct rt_context {
     uint32_t *d_bvh_index = nullptr;
 
     uint32_t *d_chunk_counter = nullptr;
+    // This device's copy of the library's static scratch array (sums, then queue heads), asked of
+    // the runtime once, in rt_create, with the device current; used by rt_render_device_static.
+    void *static_scratch = nullptr;
     // Trace launches of one context share the work queue's heads, so each waits for the one before
     // it, whatever streams the caller passes: ev_trace is recorded behind every launch.
     hipEvent_t ev_trace = nullptr;
@@ -474,6 +477,7 @@ int rt_create(int device_id, rt_context **out)
         hipEventCreate(&ctx->ev_t0) != hipSuccess || hipEventCreate(&ctx->ev_t1) != hipSuccess ||
         hipMalloc((void **)&ctx->d_chunk_counter, kQueues * kQueueStride * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_rays, 256) != hipSuccess ||
+        static_scratch_address(&ctx->static_scratch) != hipSuccess || ctx->static_scratch == nullptr ||
         hipMemset(ctx->d_rays, 0, 256) != hipSuccess) {
         rt_destroy(ctx);
         return RT_ERR_HIP;
@@ -694,7 +698,11 @@ static int render_device(rt_context *ctx, const rt_camera *cam, const rt_params 
     hipStream_t s = (hipStream_t)stream;
     uint32_t *sums = nullptr, *queue_heads = nullptr;
     if (use_static) {
-        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "no static scratch");
+        if ((uint64_t)params->width * params->height > kStaticMaxPixels)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT,
+                        "frame larger than rt_render_device_static's scratch (RT_STATIC_MAX_PIXELS = 2097152 pixels)");
+        sums = (uint32_t *)ctx->static_scratch;
+        queue_heads = (uint32_t *)((unsigned char *)ctx->static_scratch + kStaticSumsBytes);
     } else {
         const size_t sums_bytes = (size_t)params->width * params->height * 3u * sizeof(uint32_t);
         st = ensure(ctx, (void **)&ctx->d_sums, &ctx->sums_bytes, sums_bytes);
@@ -732,6 +740,11 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *par
     return render_device(ctx, cam, params, xstart, ystart, xsize, ysize, d_rgb, stream, false);
 }
 
+int rt_render_device_static(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
+                            int ystart, int xsize, int ysize, uint8_t *d_rgb, void *stream)
+{
+    return render_device(ctx, cam, params, xstart, ystart, xsize, ysize, d_rgb, stream, true);
+}
 
 int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart, int ystart,
               int xsize, int ysize, uint8_t *rgb)

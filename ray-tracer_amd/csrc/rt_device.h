@@ -111,6 +111,14 @@ struct IntersectArgs {
     BvhArgs bvh;
 };
 
+// rt_render_device_static's scratch: a file-scope device array (rt_kernels.hip) holding the
+// colour sums of a frame of up to kStaticMaxPixels pixels, then the work queue's heads.
+constexpr size_t kStaticMaxPixels = RT_STATIC_MAX_PIXELS;
+constexpr size_t kStaticSumsBytes = kStaticMaxPixels * 3u * sizeof(uint32_t);
+constexpr size_t kStaticQueueBytes = kQueues * kQueueStride * sizeof(uint32_t);
+// Device address of that array on the CURRENT device (hipGetSymbolAddress).
+hipError_t static_scratch_address(void **ptr);
+
 // Bytes of LDS between the tiles and the bounce stack for `filter`.
 uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels, uint32_t bvh_lds_nodes);
 // Bytes of dynamic LDS the trace kernel needs.

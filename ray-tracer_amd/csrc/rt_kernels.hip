@@ -681,6 +681,22 @@ __global__ void __launch_bounds__(256) intersect_kernel(const IntersectArgs a, u
 } // namespace
 
 // ---------------------------------------------------------------------------
+// Static scratch of the entry point that allocates nothing
+// ---------------------------------------------------------------------------
+
+// Per-pixel colour sums of a frame of up to kStaticMaxPixels pixels, then the work queue's heads.
+// Every GPU the library runs on holds its own copy of this array, at its own address, until the
+// process ends.  In host code the array's NAME is only a handle for hipGetSymbolAddress: the
+// kernels get the address that call returns, as an argument, like any other buffer.
+static __device__ __align__(256) unsigned char scratch[kStaticSumsBytes + kStaticQueueBytes];
+
+hipError_t static_scratch_address(void **ptr)
+{
+    *ptr = nullptr;
+    return hipGetSymbolAddress(ptr, HIP_SYMBOL(scratch));
+}
+
+// ---------------------------------------------------------------------------
 // Launch wrappers
 // ---------------------------------------------------------------------------
 

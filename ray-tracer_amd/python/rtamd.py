@@ -27,7 +27,7 @@ FILTER_AUTO, FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX, FILTER_BVH = -1, 
 # every symbol include/rt_mi355x.h declares
 EXPORTS = [
     "rt_abi_version", "rt_status_string", "rt_last_error", "rt_create", "rt_destroy", "rt_set_scene",
-    "rt_camera_init", "rt_render", "rt_render_progressive", "rt_render_device", "rt_accumulate_device", "rt_resolve_device",
+    "rt_camera_init", "rt_render", "rt_render_progressive", "rt_render_device", "rt_render_device_static", "rt_accumulate_device", "rt_resolve_device",
     "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_accel_selfcheck", "rt_get_stats", "rt_reset_stats",
 ]
 
@@ -103,6 +103,7 @@ def load():
     L.rt_camera_init.argtypes = [f3, f3, f3, C.c_float, C.POINTER(Camera)]
     L.rt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp]
     L.rt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, vp]
+    L.rt_render_device_static.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, vp]
     L.rt_accumulate_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, vp]
     L.rt_render_progressive.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, u32, PROGRESS_FN, vp]
     L.rt_accel_selfcheck.argtypes = [vp, u32, i, C.POINTER(u32 * 4)]
@@ -205,6 +206,11 @@ class Context:
         if tile is None:
             tile = (0, 0, p.width, p.height)
         self._check(self._L.rt_render_device(self._h, C.byref(cam), C.byref(p), *tile, d_rgb, stream))
+
+    def render_device_static(self, cam, p, d_rgb, tile=None, stream=None):
+        if tile is None:
+            tile = (0, 0, p.width, p.height)
+        self._check(self._L.rt_render_device_static(self._h, C.byref(cam), C.byref(p), *tile, d_rgb, stream))
 
     def accumulate_device(self, cam, p, d_sums, tile=None, stream=None):
         if tile is None:
