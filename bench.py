@@ -5,20 +5,33 @@ Workload (BASELINE.json configs[2]): the 500-sphere random-spheres scene at
 1920x1080, 64 samples per pixel, max depth 8.  One "step" = one frame.
 
   N = 1   one MI355X traces all 64 samples and resolves the RGB8 frame.
-  N > 1   weak scaling, sample-sliced: every rank traces 64 samples of every
-          pixel (the frame has 64*N spp), the per-pixel integer sums are
-          reduced to rank 0 over RCCL and rank 0 divides and packs the frame.
-          (--partition tiles: the 64*N spp are split by interleaved 8x8 tiles
-          instead; same work per rank, same reduce.)
+  N > 1   the SAME frame on N GPUs (strong scaling, the configuration the metric
+          names), split by interleaved 8x8 tiles; every rank divides and packs its
+          own tiles and the tile blocks are gathered to rank 0 over RCCL.  The
+          exchange of frame k overlaps the tracing of frame k + 1.
+          --scaling weak: every rank traces 64 samples of every pixel instead (the
+          frame has 64*N spp) and the integer sums are sum-reduced to rank 0.
+          --partition samples|tiles overrides the split.
 
 Inputs (scene, camera) and outputs (sums, frame) stay in HBM during the timed
 region.  Prints ONE JSON line on rank 0.
+
+What the line's `roofline` means.  The timed kernel walks a bounding-box hierarchy: it
+executes a few per cent of the reference's brute-force ray-sphere tests, so pricing it
+at "25 flop x spheres x rays" would exceed the machine's peak and say nothing.  Its
+`roofline` is therefore the vector ALU it actually runs on: lane-operations issued per
+launch (hardware counters of the same command, committed under profiles/) over the
+kernel's duration measured here, against the chip's VALU issue peak; the executed box
+and sphere tests (counted by the kernel itself in an untimed launch) are priced in flop
+beside it, and the brute-force-equivalent figure is kept under its own key.  The kernel
+that does perform every one of the reference's tests (the matrix-core list scan) is
+timed under the same steps/warmup protocol as a second leg, `roofline.list_scan`, with
+the fraction of the FP32 peak the survey's definition gives.
 """
 import argparse
 import json
 import os
 import re
-import subprocess
 import sys
 import time
 
@@ -35,19 +48,28 @@ import scenes
 
 W, H, SPP, DEPTH, N_SPHERES = 1920, 1080, 64, 8, 500
 
-# Other BASELINE.json configurations, selectable with --workload (the default and the headline
-# number is "c3"): name -> (width, height, frame spp or None for 64 per GPU, spheres, grid, partition)
+# BASELINE.json configurations: name -> (width, height, frame spp, spheres, grid, partition for N > 1)
 WORKLOADS = {
-    # configs[2]; weak scaling: 64 spp per GPU.  Sample slices: a rank's 1/N of the tiles at 64*N spp
-    # measured 0.26 ms slower at N = 8 (tools/share_time.py), about what its smaller exchange saves
-    "c3": (1920, 1080, None, 500, 11, "samples"),
+    "c3": (1920, 1080, 64, 500, 11, "tiles"),       # configs[2], the one the metric is quoted on
     "c4": (3840, 2160, 1024, 500, 11, "samples"),   # configs[3]: 1024 spp split over the GPUs
     "c5": (1920, 1080, 256, 10000, 50, "tiles"),    # configs[4]: 10k spheres, tile-partitioned
+}
+WORKLOAD_TEXT = {
+    "c3": "random-spheres scene, 500 spheres, 1920x1080, 64 spp, max depth 8 (BASELINE configs[2])",
+    "c4": "random-spheres scene, 500 spheres, 3840x2160, 1024 spp, max depth 8 (BASELINE configs[3])",
+    "c5": "random-spheres scene, 10000 spheres, 1920x1080, 256 spp, max depth 8 (BASELINE configs[4])",
 }
 SCANS = {"auto": rtamd.FILTER_AUTO, "exact": rtamd.FILTER_EXACT, "vector": rtamd.FILTER_CONSERVATIVE,
          "matrix": rtamd.FILTER_MATRIX, "hierarchy": rtamd.FILTER_BVH}
 FLOP_PER_TEST = 25.0          # miss path of RaySphereIntersectionTest, Source/main.cpp:475-479
-PEAK_FP32_TFLOPS = 157.3      # MI355X FP32, matrix (v_mfma_f32_*_f32) = vector: 256 CU x 128 FMA lanes x 2 x 2.4 GHz
+# One visit of an inner node tests both children's boxes: 12 plane distances of two fused
+# multiply-adds each (48 flop) and 12 min/max (rt_bvh_walk.h).
+FLOP_PER_NODE_VISIT = 60.0
+FLOP_PER_ROOT = 6.0           # negate, subtract, sqrt, divide, two range compares (Source/main.cpp:490-499)
+PEAK_FP32_TFLOPS = 157.3      # 256 CU x 128 FMA lanes x 2 flop x 2.4 GHz (matrix f32 = vector f32 on gfx950)
+PEAK_VALU_TLANEOPS = 78.6     # 256 CU x 4 SIMD x 32 lanes per clock x 2.4 GHz: one wave64 instruction per 2 cycles
+# rocprofv3 evidence of this build's `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`
+PROFILE_DIR = os.path.join("profiles", "r02_start")
 
 
 def cpu_baseline(scene):
@@ -89,14 +111,37 @@ def cpu_baseline(scene):
     return out
 
 
+def load_profile(scan):
+    """Per-launch counters of `scan`'s trace kernel from the committed rocprofv3 passes, or None."""
+    path = os.path.join(ROOT, PROFILE_DIR, "pmc_trace_kernel.json")
+    try:
+        for name, rec in json.load(open(path)).items():
+            if name.startswith(scan + " scan") and name.endswith(", 0>"):  # the plain build, not the counting one
+                return rec
+    except Exception:
+        pass
+    return None
+
+
+def load_traffic(scan):
+    try:
+        return json.load(open(os.path.join(ROOT, PROFILE_DIR, "hbm_traffic.json")))["hbm_bytes_per_launch"].get(scan)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the workload's frame split over the GPUs; weak = its spp per GPU")
     ap.add_argument("--partition", choices=["samples", "tiles"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the list-scan leg and the counting launches (N = 1 only has them)")
     ap.add_argument("--scan", choices=sorted(SCANS), default="auto",
                     help="how rays find their candidate spheres (all give the same frame); auto = the library's choice")
     args = ap.parse_args()
@@ -113,10 +158,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    global W, H, N_SPHERES
-    W, H, frame_spp, N_SPHERES, grid, default_partition = WORKLOADS[args.workload]
+    global W, H, SPP, N_SPHERES
+    W, H, SPP, N_SPHERES, grid, default_partition = WORKLOADS[args.workload]
     if args.partition is None:
-        args.partition = default_partition
+        args.partition = default_partition if args.scaling == "strong" else "samples"
     ctx = rtamd.Context(local_rank)
     scene = scenes.random_spheres(N_SPHERES, grid_half=grid)
     ctx.set_scene(scene)
@@ -125,33 +170,31 @@ def main():
     if scan == "auto":  # the library's rule (rt_mi355x.h, RT_OPT_FILTER)
         scan = "hierarchy" if N_SPHERES >= 64 else "vector"
     cam = rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA)
-    total_spp = SPP * world if frame_spp is None else frame_spp
+    total_spp = SPP * world if args.scaling == "weak" else SPP
     p = dist_render.rank_params(W, H, total_spp, DEPTH, 1, args.partition, rank, world)
     tracer = dist_render.DeviceTracer(ctx, cam)
 
-    d_sums = torch.zeros(W * H * 3, dtype=torch.int32, device="cuda")
-    d_rgb = torch.zeros(W * H * 3, dtype=torch.uint8, device="cuda")
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-
     class TimedTracer:
         """Brackets the trace kernel with events on the stream it is launched on."""
-        k = None
+
+        def __init__(self):
+            self.events = None
 
         def accumulate(self, params, sums):
-            if self.k is not None:
-                ev0[self.k].record()
+            if self.events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             tracer.accumulate(params, sums)
-            if self.k is not None:
-                ev1[self.k].record()
+            if self.events is not None:
+                e1.record()
+                self.events.append((e0, e1))
 
         resolve = staticmethod(tracer.resolve)
+        pack_tiles = staticmethod(tracer.pack_tiles)
+        unpack_tiles = staticmethod(tracer.unpack_tiles)
 
     timed = TimedTracer()
-
-    def step(k=None):
-        timed.k = k
-        dist_render.trace_frame(timed, p, d_sums, d_rgb, rank, world, dist)
+    pipe = dist_render.FramePipeline(timed, p, (W, H, total_spp), args.partition, rank, world, dist, torch, "cuda")
 
     def fence():
         torch.cuda.synchronize()
@@ -159,36 +202,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ctx.reset_stats()
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    fence()
-    elapsed = time.perf_counter() - t0
+    def run_leg(steps, warmup):
+        """`warmup` untimed frames, then `steps` timed ones -> (seconds, mean kernel ms, stats)."""
+        timed.events = None
+        for _ in range(warmup):
+            pipe.submit()
+        pipe.finish()
+        fence()
+        ctx.reset_stats()
+        fence()
+        timed.events = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.submit()
+        pipe.finish()
+        fence()
+        seconds = time.perf_counter() - t0
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in timed.events])) if timed.events else 0.0
+        timed.events = None
+        return seconds, kernel_ms, ctx.stats()
 
-    st = ctx.stats()
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    elapsed, kernel_ms, st = run_leg(args.steps, args.warmup)
 
-    # The hierarchy skips most of the reference's ray-sphere tests, so its time says nothing about
-    # how well the FP32 pipe is used.  For that, the kernel that does perform every test (the
-    # matrix-core list scan) is timed beside it on rank 0, outside the timed region.
-    list_ms = None
-    if rank == 0 and scan == "hierarchy" and N_SPHERES <= 2000:
-        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_MATRIX)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        tracer.accumulate(p, d_sums)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(3):
-            tracer.accumulate(p, d_sums)
-        e1.record()
-        torch.cuda.synchronize()
-        list_ms = e0.elapsed_time(e1) / 3.0
+    # ---- second leg and counting launches (one GPU only: they are about the kernels, not the exchange)
+    extra = world == 1 and not args.no_extra_legs and N_SPHERES <= 2000
+    list_leg = counted = None
+    if extra:
+        def count_work(filt):
+            ctx.set_option(rtamd.OPT_FILTER, filt)
+            ctx.set_option(rtamd.OPT_COUNT_WORK, 1)
+            ctx.reset_stats()
+            pipe.submit()
+            pipe.finish()
+            s = ctx.stats()
+            ctx.set_option(rtamd.OPT_COUNT_WORK, 0)
+            return {"rays": s.rays, "node_visits": s.node_visits, "exact_tests": s.exact_tests,
+                    "root_evaluations": s.root_evaluations}
+
+        counted = {scan: count_work(SCANS[args.scan])}
+        if scan == "hierarchy":
+            ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_MATRIX)
+            l_elapsed, l_kernel_ms, l_st = run_leg(args.steps, args.warmup)
+            list_leg = (l_elapsed, l_kernel_ms, l_st)
+            counted["matrix"] = count_work(rtamd.FILTER_MATRIX)
         ctx.set_option(rtamd.OPT_FILTER, SCANS[args.scan])
+
     if world > 1:
         dist.barrier()
     t = torch.tensor([elapsed, float(st.rays), float(st.wave_passes), kernel_ms], dtype=torch.float64, device="cuda")
@@ -205,15 +263,12 @@ def main():
 
     if rank == 0:
         rays_per_launch = st.rays / args.steps  # this rank's launches
-        flop_per_launch = rays_per_launch * N_SPHERES * FLOP_PER_TEST
-        achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath) and args.workload == "c3":
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch", {}).get(scan)
-            except Exception:
-                traffic = None
+        kernel_s = kernel_ms * 1e-3
+        ref_equiv = rays_per_launch * N_SPHERES * FLOP_PER_TEST / kernel_s / 1e12
+        collective = "none"
+        if world > 1:
+            collective = ("gather(uint8, %d bytes per rank) to rank 0" % pipe.block_bytes if args.partition == "tiles"
+                          else "reduce(sum, int32, %d) to rank 0" % (W * H * 3))
         line = {
             "metric": "Mrays/s (incl. bounces) at 1080p 64spp" if args.workload == "c3" else "Mrays/s (incl. bounces)",
             "value": total_rays / elapsed / 1e6,
@@ -223,55 +278,90 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak" if frame_spp is None else "strong",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": {"c3": "random-spheres scene, 500 spheres, 1920x1080, 64 spp per GPU, max depth 8 (BASELINE configs[2])",
-                             "c4": "random-spheres scene, 500 spheres, 3840x2160, 1024 spp per frame, max depth 8 (BASELINE configs[3])",
-                             "c5": "random-spheres scene, 10000 spheres, 1920x1080, 256 spp per frame, max depth 8 (BASELINE configs[4])"}[args.workload],
+                "workload": WORKLOAD_TEXT[args.workload] + (" per GPU (weak scaling)" if world > 1 and args.scaling == "weak" else ""),
                 "spheres": N_SPHERES, "width": W, "height": H, "frame_spp": total_spp,
                 "max_depth": DEPTH, "partition": args.partition if world > 1 else "none (one GPU)", "scan": scan,
-                "collective": ("none" if world == 1 else
-                               "reduce(sum,%s,%d) to rank 0" % ("uint8" if args.partition == "tiles" else "int32", W * H * 3)),
+                "collective": collective,
+                "overlap": "exchange of frame k runs beside the tracing of frame k + 1" if world > 1 else "none",
             },
             "rays_per_step": total_rays / args.steps,
             "lane_utilisation": total_rays / (64.0 * total_passes) if total_passes else None,
             "kernel_ms": kernel_ms,
             "kernel_ms_max_over_ranks": kernel_ms_max,
-            "roofline": {
-                "bound": "mfma", "pipe": "FP32 matrix/vector ALU (one shared pipe on gfx950)",
-                "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                "flop_per_unit": "25 flop per ray-sphere test x %d spheres per ray" % N_SPHERES,
-                "kernel": "trace_kernel, %s scan" % scan,
-            },
         }
-        # what the kernel executes, from the committed counter passes of the same command (profiles/)
-        ppath = os.path.join(ROOT, "profiles", "r01_last", "pmc_trace_kernel.json")
-        if os.path.exists(ppath) and args.workload == "c3":
-            try:
-                for name, rec in json.load(open(ppath)).items():
-                    if name.startswith(scan + " scan") and "derived" in rec:
-                        d = rec["derived"]
-                        line["roofline"]["executed"] = {
-                            "source": "profiles/r01_last/pmc_trace_kernel.json (rocprofv3 --pmc, separate passes)",
-                            "valu_instructions_per_launch": rec.get("SQ_INSTS_VALU"),
-                            "valu_instructions_per_cycle_per_simd": d.get("valu_instructions_per_cycle_per_simd"),
-                            "resident_waves_per_simd": d.get("resident_waves_per_simd"),
-                            "note": "wave64 VALU instructions issue every 2.3 or 4.7 cycles on this chip (measured), so "
-                                    "about 0.3 per cycle per SIMD is back-to-back issue for this mix",
-                        }
-            except Exception:
-                pass
-        if scan == "hierarchy":
-            line["roofline"]["note"] = ("algorithmic work = the reference's brute-force tests; the hierarchy skips most of "
-                                        "them, so frac can exceed 1 -- see list_scan for the kernel that performs them all")
-            if list_ms:
-                a_list = flop_per_launch / (list_ms * 1e-3) / 1e12
-                line["roofline"]["list_scan"] = {"kernel": "trace_kernel, matrix scan", "kernel_ms": list_ms,
-                                                 "achieved": a_list, "frac": a_list / PEAK_FP32_TFLOPS}
+
+        # ---- roofline of the timed kernel
+        prof = load_profile(scan) if args.workload == "c3" and world == 1 else None
+        roof = {"kernel": "trace_kernel, %s scan" % scan, "kernel_ms": kernel_ms}
+        if scan in ("matrix", "vector", "exact"):
+            # a list scan performs every one of the reference's tests: the survey's definition applies
+            roof.update({"bound": "mfma" if scan == "matrix" else "valu",
+                         "pipe": "FP32 matrix/vector ALU (one shared pipe on gfx950)",
+                         "achieved": ref_equiv, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ref_equiv / PEAK_FP32_TFLOPS,
+                         "flop_per_unit": "25 flop per ray-sphere test x %d spheres per ray" % N_SPHERES})
+        else:
+            roof.update({"bound": "valu", "pipe": "vector ALU issue (the kernel executes no MFMA)",
+                         "achieved": None, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlaneop/s", "frac": None})
+            if prof and "SQ_INSTS_VALU" in prof and "derived" in prof and prof["derived"].get("valu_active_lane_share"):
+                d = prof["derived"]
+                lane_ops = prof["SQ_INSTS_VALU"] * 64.0 * d["valu_active_lane_share"]
+                roof.update({
+                    "achieved": lane_ops / kernel_s / 1e12,
+                    "frac": lane_ops / kernel_s / 1e12 / PEAK_VALU_TLANEOPS,
+                    "lane_ops_per_launch": lane_ops,
+                    "valu_instructions_per_launch": prof["SQ_INSTS_VALU"],
+                    "valu_active_lane_share": d["valu_active_lane_share"],
+                    "valu_issue_busy_min": d.get("pipe_busy_min"),
+                    "resident_waves_per_simd": d.get("resident_waves_per_simd"),
+                    "basis": "lane-operations per launch = SQ_INSTS_VALU x 64 x SQ_THREAD_CYCLES_VALU / (64 x "
+                             "SQ_ACTIVE_INST_VALU), rocprofv3 --pmc passes of this command in %s; duration = this "
+                             "run's events; peak = one wave64 instruction per 2 cycles per SIMD; valu_issue_busy_min = "
+                             "SQ_INSTS_VALU x 2 cycles / SIMD-cycles (a lower bound: about half of the mix issues in 4)" % PROFILE_DIR,
+                })
+            # the brute-force-equivalent rate: a speed-up figure, NOT a utilisation (the walk skips most tests)
+            roof["reference_equivalent_tflops"] = ref_equiv
+        roof["traffic"] = load_traffic(scan) if args.workload == "c3" and world == 1 else None
+        if counted and scan in counted:
+            c = counted[scan]
+            flop = (c["node_visits"] * FLOP_PER_NODE_VISIT + c["exact_tests"] * FLOP_PER_TEST +
+                    c["root_evaluations"] * FLOP_PER_ROOT)
+            roof["executed_tests"] = dict(c, flop_per_launch=flop, tflops=flop / kernel_s / 1e12,
+                                          frac_of_fp32_peak=flop / kernel_s / 1e12 / PEAK_FP32_TFLOPS,
+                                          per_ray={"node_visits": c["node_visits"] / max(c["rays"], 1),
+                                                   "exact_tests": c["exact_tests"] / max(c["rays"], 1),
+                                                   "root_evaluations": c["root_evaluations"] / max(c["rays"], 1)},
+                                          pricing="60 flop per node visit (two boxes), 25 per discriminant, 6 per root; "
+                                                  "counted by the kernel's counting build in an untimed launch")
+        if list_leg:
+            l_elapsed, l_kernel_ms, l_st = list_leg
+            l_rays = l_st.rays / args.steps
+            a_list = l_rays * N_SPHERES * FLOP_PER_TEST / (l_kernel_ms * 1e-3) / 1e12
+            leg = {
+                "kernel": "trace_kernel, matrix scan (performs every one of the reference's ray-sphere tests)",
+                "steps": args.steps, "warmup": args.warmup,
+                "value": l_st.rays / l_elapsed / 1e6, "unit_value": "Mrays/s",
+                "ms_per_step": l_elapsed / args.steps * 1e3, "kernel_ms": l_kernel_ms,
+                "bound": "mfma", "pipe": "FP32 matrix/vector ALU (one shared pipe on gfx950)",
+                "achieved": a_list, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": a_list / PEAK_FP32_TFLOPS,
+                "flop_per_unit": "25 flop per ray-sphere test x %d spheres per ray" % N_SPHERES,
+                "traffic": load_traffic("matrix") if args.workload == "c3" else None,
+            }
+            lp = load_profile("matrix") if args.workload == "c3" else None
+            if lp and "derived" in lp:
+                leg["executed"] = {k: lp["derived"].get(k) for k in
+                                   ("mfma_pipe_share", "pipe_busy_min", "valu_active_lane_share", "resident_waves_per_simd")}
+                leg["executed"]["mfma_instructions_per_launch"] = lp.get("SQ_INSTS_MFMA")
+                leg["executed"]["valu_instructions_per_launch"] = lp.get("SQ_INSTS_VALU")
+            if counted and "matrix" in counted:
+                leg["executed_tests"] = counted["matrix"]
+            roof["list_scan"] = leg
+        line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             line["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(line), flush=True)

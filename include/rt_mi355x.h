@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -112,6 +112,13 @@ typedef struct rt_stats {
                                  is the fraction of lanes that carried a ray */
     double   last_kernel_ms;  /* device time of the last synchronous call's kernels */
     double   last_wall_ms;    /* host wall time of the last synchronous call */
+    /* Work the chosen scan EXECUTED for these rays, tallied only while RT_OPT_COUNT_WORK is 1 (a
+     * slower build of the trace kernel, same results; the rt_params.flags extensions are not
+     * tallied), 0 otherwise: */
+    uint64_t node_visits;     /* inner nodes of the hierarchy visited, two box tests each (RT_OPT_FILTER 3) */
+    uint64_t exact_tests;     /* evaluations of the reference's discriminant (Source/main.cpp:475-479);
+                                 equals sphere_tests for RT_OPT_FILTER 0 */
+    uint64_t root_evaluations; /* of those, the ones that went on to sqrt and divide (Source/main.cpp:490-499) */
 } rt_stats;
 
 typedef struct rt_context rt_context;
@@ -191,6 +198,22 @@ int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, u
                       uint32_t spp_div, uint32_t flags, int xstart, int ystart, int xsize, int ysize,
                       uint8_t *d_rgb, void *stream);
 
+/* Tile partition of one frame over several devices (the reference's partition is TraceScene's
+ * four column strips, Source/main.cpp:647-659; here a device takes the 8x8 tiles tile_first,
+ * tile_first + tile_stride, ... of the whole frame, numbered row by row, which balances sky
+ * against ground).  rt_pack_tiles_device is rt_resolve_device for exactly those tiles, written one
+ * after the other into `d_tiles` (rt_tile_block_bytes() bytes: 192 per tile, pixel (lx, ly) of a
+ * tile at (ly*8 + lx)*3; pixels of an edge tile outside the frame are 0) -- the block a device
+ * contributes to a gather.  rt_unpack_tiles_device is PutPixel (Source/main.cpp:273-281) for the
+ * gathered blocks of all `n_blocks` devices (block b = what the device with tile_first b and
+ * tile_stride n_blocks packed; consecutive blocks block_bytes apart) into the RGB8 frame. */
+uint64_t rt_tile_block_bytes(uint32_t width, uint32_t height, uint32_t tile_first, uint32_t tile_stride);
+int rt_pack_tiles_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, uint32_t height,
+                         uint32_t spp_div, uint32_t flags, uint32_t tile_first, uint32_t tile_stride,
+                         uint8_t *d_tiles, void *stream);
+int rt_unpack_tiles_device(rt_context *ctx, const uint8_t *d_blocks, uint32_t n_blocks, uint64_t block_bytes,
+                           uint32_t width, uint32_t height, uint8_t *d_rgb, void *stream);
+
 /* Deterministic primary-ray map: for every pixel, the index of the sphere that
  * IntersectSceneSpheres (Source/main.cpp:528-549) selects for the ray through
  * the pixel centre (jitter 0.5, tmin 0.001f, tmax +inf), or -1.  hits[x + y*width]. */
@@ -228,7 +251,9 @@ typedef enum rt_option {
                                      per resident wave cuts each tile into 2 or 4 strips of rows and then its samples
                                      into segments, chunks of at least 256 paths; segments add into the frame with
                                      atomics (0..256, default 16, 0 = never cut).  Results do not depend on it. */
-    RT_OPT_SUBTILES = 8           /* most strips of rows a tile is cut into before its samples are: 1, 2 or 4 (default) */
+    RT_OPT_SUBTILES = 8,          /* most strips of rows a tile is cut into before its samples are: 1, 2 or 4 (default) */
+    RT_OPT_COUNT_WORK = 9         /* 1: trace with the counting build, which fills rt_stats' node_visits, exact_tests and
+                                     root_evaluations (slower; for measurement); 0 (default): those stay 0 */
 } rt_option;
 
 int rt_set_option(rt_context *ctx, int option, int64_t value);

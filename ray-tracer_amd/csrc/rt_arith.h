@@ -14,6 +14,14 @@
 namespace rtamd {
 namespace {
 
+// Per-lane tally of the work a scan executes, kept only by the counting build of the trace kernel
+// (RT_OPT_COUNT_WORK); everywhere else the pointer is a compile-time null and the code vanishes.
+struct WorkCount {
+    uint32_t nodes; // inner nodes of the hierarchy visited (two box tests each)
+    uint32_t exact; // evaluations of the reference's discriminant (Source/main.cpp:475-479)
+    uint32_t roots; // of those, evaluations that went on to the square root and the division (:490-499)
+};
+
 // ---------------------------------------------------------------------------
 // Counter-based random numbers
 // ---------------------------------------------------------------------------
@@ -171,12 +179,16 @@ __device__ __forceinline__ float discriminant(const RayState &r, const Geom &s, 
 // true when the sphere becomes the closest hit (an equal T is accepted, so the
 // later sphere wins a tie).
 __device__ __forceinline__ bool resolve_candidate(const RayState &r, const Geom &s, float tmin,
-                                                  float &closest)
+                                                  float &closest, WorkCount *wc = nullptr)
 {
     float B;
     const float disc = discriminant(r, s, B);
+    if (wc)
+        ++wc->exact;
     if (disc < 0.0f)
         return false;
+    if (wc)
+        ++wc->roots;
     const float sq = sqrtf(disc);
     float root = (-B - sq) / r.two_a;
     if (root < tmin || root > closest) {
@@ -191,12 +203,16 @@ __device__ __forceinline__ bool resolve_candidate(const RayState &r, const Geom 
 // Effective root of RaySphereIntersectionTest (Source/main.cpp:490-499) for a
 // ray without NaNs: the near root if it is >= tmin, else the far root.
 __device__ __forceinline__ void resolve_unordered(const RayState &r, const Geom &s, int idx, float tmin,
-                                                  float &closest, int &best)
+                                                  float &closest, int &best, WorkCount *wc = nullptr)
 {
     float B;
     const float disc = discriminant(r, s, B);
+    if (wc)
+        ++wc->exact;
     if (disc < 0.0f)
         return;
+    if (wc)
+        ++wc->roots;
     const float sq = sqrtf(disc);
     float root = (-B - sq) / r.two_a;
     if (root < tmin)

@@ -80,12 +80,12 @@ constexpr int kBvhDone = INT_MIN;
 
 // Start of a ray's walk: the always-tested spheres, then the root.
 __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, float tmin, int &node, uint32_t &sp,
-                                          float &closest, int &best)
+                                          float &closest, int &best, WorkCount *wc = nullptr)
 {
     closest = INFINITY;
     best = -1;
     for (uint32_t i = 0; i < b.n_large; ++i)
-        resolve_unordered(r, b.leaf_geom[i], (int)b.leaf_index[i], tmin, closest, best);
+        resolve_unordered(r, b.leaf_geom[i], (int)b.leaf_index[i], tmin, closest, best, wc);
     node = b.n_nodes ? 0 : kBvhDone;
     sp = 0u;
 }
@@ -94,7 +94,7 @@ __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, f
 template <bool NODES_IN_LDS>
 __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nodes, const RayState &r,
                                          uint32_t *stk, bool walking, float tmin, int &node, uint32_t &sp,
-                                         float &closest, int &best)
+                                         float &closest, int &best, WorkCount *wc = nullptr)
 {
     if (!walking)
         node = kBvhDone;
@@ -135,6 +135,8 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
     constexpr int kDone = kBvhDone;
     while ((uint32_t)__popcll(__ballot(node != kDone)) > suspend) {
         while (node >= 0) {
+            if (wc)
+                ++wc->nodes;
             const float4 *np = (NODES_IN_LDS ? lds_nodes : b.nodes) + (size_t)node * 4u;
             const float4 l0 = np[0], h0 = np[1], l1 = np[2], h1 = np[3];
 #define RT_SLAB(lo, hi, na, nb, nc) __builtin_fmaf(lo, na, __builtin_fmaf(hi, nb, nc))
@@ -184,6 +186,10 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
                 Bj[j] = dj[j] = 0.0f;
                 if (i0 + j < count && leaf_candidate(r, g[j], Bj[j], dj[j]))
                     cand |= 1u << j;
+            }
+            if (wc) {
+                wc->exact += min(4u, count - i0);
+                wc->roots += (uint32_t)__popc(cand);
             }
             while (cand != 0u) {
                 const uint32_t j = (uint32_t)__builtin_ctz(cand);

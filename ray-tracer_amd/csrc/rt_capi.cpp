@@ -49,6 +49,7 @@ struct rt_context {
     uint32_t bvh_lds_nodes_max = 512; // trees up to this many nodes (64 B each) are walked in LDS
     uint32_t subtiles_max = 4;     // work queue: tiles may be cut into this many strips of rows (1, 2 or 4)
     uint32_t chunks_per_wave = 16; // work queue: split tiles' samples until there are this many chunks per resident wave
+    bool count_work = false;       // RT_OPT_COUNT_WORK: launch the counting build of the trace kernel
     uint32_t bvh_auto_min = 64;    // automatic choice: hierarchy from this many spheres up (measured crossover)
     float4 *d_bvh_nodes = nullptr;
     Geom *d_bvh_geom = nullptr;
@@ -330,6 +331,7 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     a.sample_count = p->sample_count ? p->sample_count : p->spp;
     a.max_depth = p->max_depth;
     a.flags = p->flags;
+    a.count_work = ctx->count_work ? 1u : 0u;
     a.key0 = (uint32_t)p->seed;
     a.key1 = (uint32_t)(p->seed >> 32);
     a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
@@ -847,6 +849,72 @@ int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params
     return RT_OK;
 }
 
+static uint32_t own_tiles(uint32_t width, uint32_t height, uint32_t first, uint32_t stride)
+{
+    const uint64_t n = (uint64_t)((width + kTileW - 1) / kTileW) * ((height + kTileH - 1) / kTileH);
+    if (stride == 0u)
+        stride = 1u;
+    return first < n ? (uint32_t)((n - first + stride - 1u) / stride) : 0u;
+}
+
+uint64_t rt_tile_block_bytes(uint32_t width, uint32_t height, uint32_t tile_first, uint32_t tile_stride)
+{
+    return (uint64_t)own_tiles(width, height, tile_first, tile_stride) * (uint64_t)(kTileW * kTileH * 3);
+}
+
+int rt_pack_tiles_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, uint32_t height,
+                         uint32_t spp_div, uint32_t flags, uint32_t tile_first, uint32_t tile_stride,
+                         uint8_t *d_tiles, void *stream)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
+    if (!d_sums || !d_tiles || width == 0 || height == 0 || spp_div == 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad pack arguments");
+    if ((uint64_t)width * height > (1ull << 30))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "frame larger than 2^30 pixels");
+    if ((flags & ~(uint32_t)RT_FLAG_GAMMA2) != 0u)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_pack_tiles_device takes RT_FLAG_GAMMA2 only");
+    if (tile_stride == 0u)
+        tile_stride = 1u;
+    if (tile_first >= tile_stride)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "tile_first must be below tile_stride");
+    RT_DEVICE(ctx);
+    TilesArgs a;
+    memset(&a, 0, sizeof a);
+    a.sums = d_sums; a.tiles = d_tiles;
+    a.width = width; a.height = height;
+    a.tiles_x = (width + kTileW - 1) / kTileW; a.tiles_y = (height + kTileH - 1) / kTileH;
+    a.spp_div = spp_div; a.flags = flags;
+    a.tile_first = tile_first; a.tile_stride = tile_stride;
+    a.n_own = own_tiles(width, height, tile_first, tile_stride);
+    RT_HIP(ctx, launch_pack_tiles(a, (hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_unpack_tiles_device(rt_context *ctx, const uint8_t *d_blocks, uint32_t n_blocks, uint64_t block_bytes,
+                           uint32_t width, uint32_t height, uint8_t *d_rgb, void *stream)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
+    if (!d_blocks || !d_rgb || width == 0 || height == 0 || n_blocks == 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad unpack arguments");
+    if ((uint64_t)width * height > (1ull << 30))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "frame larger than 2^30 pixels");
+    if (block_bytes < rt_tile_block_bytes(width, height, 0u, n_blocks))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "block_bytes smaller than the first device's block");
+    RT_DEVICE(ctx);
+    TilesArgs a;
+    memset(&a, 0, sizeof a);
+    a.tiles_in = d_blocks; a.rgb = d_rgb;
+    a.width = width; a.height = height;
+    a.tiles_x = (width + kTileW - 1) / kTileW; a.tiles_y = (height + kTileH - 1) / kTileH;
+    a.n_blocks = n_blocks; a.block_bytes = (size_t)block_bytes;
+    RT_HIP(ctx, launch_unpack_tiles(a, (hipStream_t)stream));
+    return RT_OK;
+}
+
 int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width, uint32_t height,
                            int32_t *d_hits, void *stream)
 {
@@ -1007,6 +1075,11 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_SUBTILES takes 1, 2 or 4");
         ctx->subtiles_max = (uint32_t)value;
         return RT_OK;
+    case RT_OPT_COUNT_WORK:
+        if (value != 0 && value != 1)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_COUNT_WORK takes 0 or 1");
+        ctx->count_work = value == 1;
+        return RT_OK;
     case RT_OPT_BVH_MIN_SPHERES:
         if (value < 1 || value > (1ll << 30))
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_MIN_SPHERES takes 1..2^30");
@@ -1060,8 +1133,11 @@ int rt_get_stats(rt_context *ctx, rt_stats *stats)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null stats");
     RT_DEVICE(ctx);
     RT_HIP(ctx, hipDeviceSynchronize());
-    unsigned long long counters[2] = { 0, 0 };
+    unsigned long long counters[5] = { 0, 0, 0, 0, 0 };
     RT_HIP(ctx, hipMemcpy(counters, ctx->d_rays, sizeof counters, hipMemcpyDeviceToHost));
+    stats->node_visits = counters[2];
+    stats->exact_tests = counters[3];
+    stats->root_evaluations = counters[4];
     stats->rays = counters[0];
     stats->sphere_tests = counters[0] * (uint64_t)ctx->n_spheres;
     stats->wave_passes = counters[1];
@@ -1077,7 +1153,7 @@ int rt_reset_stats(rt_context *ctx)
     std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     RT_DEVICE(ctx);
     RT_HIP(ctx, hipDeviceSynchronize());
-    RT_HIP(ctx, hipMemset(ctx->d_rays, 0, 2 * sizeof(unsigned long long)));
+    RT_HIP(ctx, hipMemset(ctx->d_rays, 0, 5 * sizeof(unsigned long long)));
     ctx->last_kernel_ms = ctx->last_wall_ms = 0.0;
     return RT_OK;
 }

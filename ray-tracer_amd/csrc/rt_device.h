@@ -63,6 +63,7 @@ struct TraceArgs {
     uint32_t sample_begin, sample_count;
     int32_t max_depth;
     uint32_t flags;            // RT_FLAG_*
+    uint32_t count_work;       // launch the counting build: tallies of executed work go to rays[2..4]
     uint32_t key0, key1;
     int32_t x0, y0, w, h;      // traced region
     uint32_t tiles_x, tiles_y; // 8x8 tiles of the region
@@ -74,7 +75,8 @@ struct TraceArgs {
     // edge is an empty chunk.  With segments > 1 several waves add into the same pixels of `sums`.
     uint32_t n_chunks, subtiles, segments, seg_samples;
     uint32_t *sums;            // full frame uint32 x3
-    unsigned long long *rays;  // [0] ray counter, [1] wave passes over the sphere list
+    unsigned long long *rays;  // [0] ray counter, [1] wave passes over the sphere list; counting build:
+                               // [2] hierarchy nodes visited, [3] exact discriminants, [4] root evaluations
     // Work queue heads, zeroed before launch: kQueues counters kQueueStride words apart; queue q
     // hands out chunks q, q + kQueues, q + 2 kQueues, ...
     uint32_t *chunk_counter;
@@ -85,6 +87,19 @@ struct ResolveArgs {
     uint8_t *rgb;
     uint32_t width, height, spp_div, flags;
     int32_t x0, y0, w, h;
+};
+
+// Tile-major exchange buffers of a tile partition (pack_tiles_kernel, unpack_tiles_kernel).
+struct TilesArgs {
+    const uint32_t *sums;      // pack: full-frame sums
+    uint8_t *tiles;            // pack: n_own x 192 bytes out
+    const uint8_t *tiles_in;   // unpack: n_blocks blocks of block_bytes
+    uint8_t *rgb;              // unpack: the frame
+    uint32_t width, height, tiles_x, tiles_y;
+    uint32_t spp_div, flags;
+    uint32_t tile_first, tile_stride, n_own; // pack: this device's tiles
+    uint32_t n_blocks;         // unpack: devices
+    size_t block_bytes;        // unpack: bytes between two devices' blocks
 };
 
 struct HitsArgs {
@@ -126,6 +141,8 @@ size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth,
 
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream);
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream);
+hipError_t launch_pack_tiles(const TilesArgs &a, hipStream_t stream);
+hipError_t launch_unpack_tiles(const TilesArgs &a, hipStream_t stream);
 hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream);
 hipError_t launch_intersect(const IntersectArgs &a, hipStream_t stream);
 // Resident workgroups per CU of the trace kernel at this LDS size.

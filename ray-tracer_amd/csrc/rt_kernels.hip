@@ -140,9 +140,17 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
 // (Source/main.cpp:551-598, 613-645), iterative.
 // ---------------------------------------------------------------------------
 
-template <bool MULTI_TILE, int FILTER, bool EXT>
+// VARIANT: kPlain the reference's behaviour and nothing else; kExt with the rt_params.flags
+// extensions compiled in; kCount kPlain plus per-lane tallies of the work the scan executes
+// (RT_OPT_COUNT_WORK; slower, same results).
+enum { kPlain = 0, kExt = 1, kCount = 2 };
+
+template <bool MULTI_TILE, int FILTER, int VARIANT>
 __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) trace_kernel(const TraceArgs a)
 {
+    constexpr bool EXT = VARIANT == kExt;
+    WorkCount work = { 0u, 0u, 0u };
+    WorkCount *const wc = VARIANT == kCount ? &work : nullptr;
     extern __shared__ __align__(16) unsigned char smem[];
     Geom *tile_f = reinterpret_cast<Geom *>(smem);
     Geom *tile_e = tile_f + a.tile_cap;
@@ -338,21 +346,21 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             if (active && !w_pending) { // a ray that starts its scan in this pass
                 w_pending = true;
                 if (ray.tame) {
-                    bvh_begin(a.bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best);
+                    bvh_begin(a.bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best, wc);
                 } else { // the reference's in-order loop over the whole list, from memory
                     w_closest = INFINITY;
                     w_best = -1;
                     w_node = kBvhDone;
-                    scan_tile<kFilterExact>(a.exact, a.exact, a.n, 0u, ray, 0.001f, w_closest, w_best);
+                    scan_tile<kFilterExact>(a.exact, a.exact, a.n, 0u, ray, 0.001f, w_closest, w_best, wc);
                 }
             }
             if (wave_active) {
                 uint32_t *stk = reinterpret_cast<uint32_t *>(stage) + tid;
                 const bool walking = active && w_node != kBvhDone;
                 if (a.bvh.lds_nodes)
-                    bvh_walk<true>(a.bvh, bvh_lds, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best);
+                    bvh_walk<true>(a.bvh, bvh_lds, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best, wc);
                 else
-                    bvh_walk<false>(a.bvh, nullptr, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best);
+                    bvh_walk<false>(a.bvh, nullptr, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best, wc);
             }
             if (active && w_node == kBvhDone) {
                 w_pending = false;
@@ -372,18 +380,18 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             if (FILTER == kFilterMatrix) {
                 if (wave_active)
                     scan_tile_matrix(reinterpret_cast<const float *>(tile_f), tile_e, round_up_group(cnt), t0, mo,
-                                     ray, mine, lane, 0.001f, closest, best);
+                                     ray, mine, lane, 0.001f, closest, best, wc);
                 if (active && !ray.tame) // NaN, Inf, zero or huge rays: the reference's in-order loop
-                    scan_tile<kFilterExact>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best);
+                    scan_tile<kFilterExact>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best, wc);
             } else if (active) {
                 if (FILTER == kFilterConservative && !MULTI_TILE && cnt <= kShortList) {
                     // a handful of spheres (the reference's own scene has four): its loop as it
                     // stands, :534-546 -- cheaper than a 32-record filter block that is mostly padding
                     for (uint32_t i = 0u; i < cnt; ++i)
-                        if (resolve_candidate(ray, tile_e[i], 0.001f, closest))
+                        if (resolve_candidate(ray, tile_e[i], 0.001f, closest, wc))
                             best = (int)i;
                 } else {
-                    scan_tile<FILTER>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best);
+                    scan_tile<FILTER>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best, wc);
                 }
             }
         }
@@ -565,6 +573,20 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
         atomicAdd(a.rays, total);
         atomicAdd(a.rays + 1, (unsigned long long)n_rounds);
     }
+    if (VARIANT == kCount) { // executed work: [2] node visits, [3] discriminants, [4] root evaluations
+        unsigned long long w0 = work.nodes, w1 = work.exact, w2 = work.roots;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            w0 += __shfl_down(w0, off, 64);
+            w1 += __shfl_down(w1, off, 64);
+            w2 += __shfl_down(w2, off, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(a.rays + 2, w0);
+            atomicAdd(a.rays + 3, w1);
+            atomicAdd(a.rays + 4, w2);
+        }
+    }
 }
 
 // FinalColor / SPP, ToRGB(ivec3), PutPixel -- Source/main.cpp:638-642.
@@ -584,6 +606,54 @@ __global__ void __launch_bounds__(256) resolve_kernel(const ResolveArgs a)
             q = (uint32_t)to_byte(sqrtf((float)q / 255.0f) * 255.0f);
         a.rgb[loc + c] = (uint8_t)q;
     }
+}
+
+// FinalColor / SPP, ToRGB (Source/main.cpp:638-642) for the 8x8 tiles first, first + stride, ... of
+// the frame, written tile after tile (192 bytes each, pixel (lx, ly) of a tile at (ly*8 + lx)*3)
+// instead of into the frame: the block one device of a tile partition sends to the gathering one.
+// One thread per pixel of a tile; pixels of an edge tile that lie outside the frame are written 0.
+__global__ void __launch_bounds__(256) pack_tiles_kernel(const TilesArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = i >> 6, p = i & 63u;
+    if (k >= a.n_own)
+        return;
+    const uint32_t t = a.tile_first + k * a.tile_stride;
+    const uint32_t ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const uint32_t x = tx * kTileW + (p & 7u), y = ty * kTileH + (p >> 3);
+    uint8_t *dst = a.tiles + (size_t)i * 3u;
+    if (x >= a.width || y >= a.height) {
+        dst[0] = dst[1] = dst[2] = 0;
+        return;
+    }
+    const size_t loc = ((size_t)x + (size_t)y * a.width) * 3u;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        uint32_t q = a.sums[loc + c] / a.spp_div;
+        q = q > 255u ? 255u : q;
+        if (a.flags & RT_FLAG_GAMMA2)
+            q = (uint32_t)to_byte(sqrtf((float)q / 255.0f) * 255.0f);
+        dst[c] = (uint8_t)q;
+    }
+}
+
+// The gathered blocks of all `n_blocks` devices, block b = tiles b, b + n_blocks, ... as
+// pack_tiles_kernel wrote them, each block block_bytes long: PutPixel (Source/main.cpp:273-281) of
+// every pixel into the frame.  One thread per pixel of the frame's tile grid.
+__global__ void __launch_bounds__(256) unpack_tiles_kernel(const TilesArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = i >> 6, p = i & 63u;
+    if (t >= a.tiles_x * a.tiles_y)
+        return;
+    const uint32_t ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const uint32_t x = tx * kTileW + (p & 7u), y = ty * kTileH + (p >> 3);
+    if (x >= a.width || y >= a.height)
+        return;
+    const uint32_t b = t % a.n_blocks, k = t / a.n_blocks;
+    const uint8_t *src = a.tiles_in + (size_t)b * a.block_bytes + ((size_t)k * 64u + p) * 3u;
+    uint8_t *dst = a.rgb + ((size_t)x + (size_t)y * a.width) * 3u;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
 }
 
 // Deterministic primary-ray closest-hit map (jitter 0.5): one lane per pixel,
@@ -722,16 +792,21 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
     const bool multi = a.filter != kFilterBvh && a.n > a.tile_cap;
     const dim3 grid(n_workgroups), block(kTraceThreads);
     const bool glass = (a.flags & (RT_FLAG_DIELECTRIC | RT_FLAG_FLOAT_SHADING)) != 0u; // the extended kernels
+    const bool count = a.count_work != 0u && !glass; // tallies exist for the reference's behaviour only
 #define RT_LAUNCH_TRACE(F)                                                                        \
     do {                                                                                          \
         if (multi && glass)                                                                       \
-            hipLaunchKernelGGL((trace_kernel<true, F, true>), grid, block, lds, stream, a);       \
+            hipLaunchKernelGGL((trace_kernel<true, F, kExt>), grid, block, lds, stream, a);       \
+        else if (multi && count)                                                                  \
+            hipLaunchKernelGGL((trace_kernel<true, F, kCount>), grid, block, lds, stream, a);     \
         else if (multi)                                                                           \
-            hipLaunchKernelGGL((trace_kernel<true, F, false>), grid, block, lds, stream, a);      \
+            hipLaunchKernelGGL((trace_kernel<true, F, kPlain>), grid, block, lds, stream, a);     \
         else if (glass)                                                                           \
-            hipLaunchKernelGGL((trace_kernel<false, F, true>), grid, block, lds, stream, a);      \
+            hipLaunchKernelGGL((trace_kernel<false, F, kExt>), grid, block, lds, stream, a);      \
+        else if (count)                                                                           \
+            hipLaunchKernelGGL((trace_kernel<false, F, kCount>), grid, block, lds, stream, a);    \
         else                                                                                      \
-            hipLaunchKernelGGL((trace_kernel<false, F, false>), grid, block, lds, stream, a);     \
+            hipLaunchKernelGGL((trace_kernel<false, F, kPlain>), grid, block, lds, stream, a);    \
     } while (0)
     switch (a.filter) {
     case kFilterExact: RT_LAUNCH_TRACE(kFilterExact); break;
@@ -739,9 +814,11 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
     case kFilterMatrix: RT_LAUNCH_TRACE(kFilterMatrix); break;
     case kFilterBvh:
         if (glass)
-            hipLaunchKernelGGL((trace_kernel<false, kFilterBvh, true>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((trace_kernel<false, kFilterBvh, kExt>), grid, block, lds, stream, a);
+        else if (count)
+            hipLaunchKernelGGL((trace_kernel<false, kFilterBvh, kCount>), grid, block, lds, stream, a);
         else
-            hipLaunchKernelGGL((trace_kernel<false, kFilterBvh, false>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((trace_kernel<false, kFilterBvh, kPlain>), grid, block, lds, stream, a);
         break;
     default:
         return hipErrorInvalidValue;
@@ -754,12 +831,12 @@ hipError_t trace_occupancy(int filter, size_t lds_bytes, int *workgroups_per_cu)
 {
     if (filter == kFilterBvh)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            workgroups_per_cu, trace_kernel<false, kFilterBvh, false>, kTraceThreads, lds_bytes);
+            workgroups_per_cu, trace_kernel<false, kFilterBvh, kPlain>, kTraceThreads, lds_bytes);
     if (filter == kFilterMatrix)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            workgroups_per_cu, trace_kernel<false, kFilterMatrix, false>, kTraceThreads, lds_bytes);
+            workgroups_per_cu, trace_kernel<false, kFilterMatrix, kPlain>, kTraceThreads, lds_bytes);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        workgroups_per_cu, trace_kernel<false, kFilterConservative, false>, kTraceThreads, lds_bytes);
+        workgroups_per_cu, trace_kernel<false, kFilterConservative, kPlain>, kTraceThreads, lds_bytes);
 }
 
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream)
@@ -768,6 +845,23 @@ hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream)
     if (total == 0u)
         return hipSuccess;
     hipLaunchKernelGGL(resolve_kernel, dim3((total + 255u) / 256u), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_tiles(const TilesArgs &a, hipStream_t stream)
+{
+    if (a.n_own == 0u)
+        return hipSuccess;
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3((a.n_own * 64u + 255u) / 256u), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_tiles(const TilesArgs &a, hipStream_t stream)
+{
+    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
+    if (n_tiles == 0u)
+        return hipSuccess;
+    hipLaunchKernelGGL(unpack_tiles_kernel, dim3((n_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -44,11 +44,13 @@ __device__ __forceinline__ float filter_sign(const RayState &r, const Geom &s)
 template <int FILTER>
 __device__ __forceinline__ void scan_tile(const Geom *__restrict__ filt, const Geom *__restrict__ exact,
                                           uint32_t count, uint32_t base, const RayState &r, float tmin,
-                                          float &closest, int &best)
+                                          float &closest, int &best, WorkCount *wc = nullptr)
 {
     for (uint32_t b = 0; b < count; b += kBlock) {
         uint32_t mask = 0u;
         if (FILTER == kFilterExact) {
+            if (wc) // phase 1 is the reference's own discriminant for every sphere of the block
+                wc->exact += min((uint32_t)kBlock, count - b);
 #pragma unroll
             for (int j = 0; j < kBlock; ++j) {
                 float B;
@@ -68,8 +70,10 @@ __device__ __forceinline__ void scan_tile(const Geom *__restrict__ filt, const G
         while (mask) {
             const int j = __clz((int)mask);
             mask &= ~(0x80000000u >> j);
-            if (resolve_candidate(r, exact[b + j], tmin, closest))
+            if (resolve_candidate(r, exact[b + j], tmin, closest, FILTER == kFilterExact ? nullptr : wc))
                 best = (int)(base + b + j);
+            if (FILTER == kFilterExact && wc)
+                ++wc->roots; // the discriminant was counted in phase 1
         }
     }
 }
@@ -157,7 +161,8 @@ __device__ __forceinline__ void matrix_operands(const RayState &r, bool use, flo
 __device__ __forceinline__ void scan_tile_matrix(const float *__restrict__ filt,
                                                  const Geom *__restrict__ exact, uint32_t count_padded,
                                                  uint32_t base, const MatrixOperands &m, const RayState &r,
-                                                 bool mine, int lane, float tmin, float &closest, int &best)
+                                                 bool mine, int lane, float tmin, float &closest, int &best,
+                                                 WorkCount *wc = nullptr)
 {
     const int c = lane & 15, k = lane >> 4;
     const f32x4 zero = { 0.0f, 0.0f, 0.0f, 0.0f };
@@ -220,7 +225,7 @@ __device__ __forceinline__ void scan_tile_matrix(const float *__restrict__ filt,
                 const uint32_t rest = word & ~(0x80000000u >> pos);
                 if (j == 0) o0 = rest; else if (j == 1) o1 = rest; else if (j == 2) o2 = rest; else o3 = rest;
                 const uint32_t i = g0 + 16u * (uint32_t)(pos >> 2) + 4u * (uint32_t)((k + j) & 3) + (uint32_t)(pos & 3);
-                resolve_unordered(r, exact[i], (int)(base + i), tmin, closest, best);
+                resolve_unordered(r, exact[i], (int)(base + i), tmin, closest, best, wc);
             }
         }
     }

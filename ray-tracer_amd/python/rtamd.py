@@ -22,13 +22,14 @@ OPT_FILTER, OPT_TILE_SPHERES, OPT_WORKGROUPS_PER_CU, OPT_BVH_LEAF_SPHERES, OPT_B
 OPT_BVH_SUSPEND_LANES = 6
 OPT_CHUNKS_PER_WAVE = 7
 OPT_SUBTILES = 8
+OPT_COUNT_WORK = 9
 FILTER_AUTO, FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX, FILTER_BVH = -1, 0, 1, 2, 3
 
 # every symbol include/rt_mi355x.h declares
 EXPORTS = [
     "rt_abi_version", "rt_status_string", "rt_last_error", "rt_create", "rt_destroy", "rt_set_scene",
     "rt_camera_init", "rt_render", "rt_render_progressive", "rt_render_device", "rt_render_device_static", "rt_accumulate_device", "rt_resolve_device",
-    "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_accel_selfcheck", "rt_get_stats", "rt_reset_stats",
+    "rt_tile_block_bytes", "rt_pack_tiles_device", "rt_unpack_tiles_device", "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_accel_selfcheck", "rt_get_stats", "rt_reset_stats",
 ]
 
 
@@ -64,6 +65,9 @@ class Stats(C.Structure):
         ("wave_passes", C.c_uint64),
         ("last_kernel_ms", C.c_double),
         ("last_wall_ms", C.c_double),
+        ("node_visits", C.c_uint64),
+        ("exact_tests", C.c_uint64),
+        ("root_evaluations", C.c_uint64),
     ]
 
 
@@ -108,6 +112,10 @@ def load():
     L.rt_render_progressive.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, i, i, i, vp, u32, PROGRESS_FN, vp]
     L.rt_accel_selfcheck.argtypes = [vp, u32, i, C.POINTER(u32 * 4)]
     L.rt_resolve_device.argtypes = [vp, vp, u32, u32, u32, u32, i, i, i, i, vp, vp]
+    L.rt_tile_block_bytes.argtypes = [u32, u32, u32, u32]
+    L.rt_tile_block_bytes.restype = C.c_uint64
+    L.rt_pack_tiles_device.argtypes = [vp, vp, u32, u32, u32, u32, u32, u32, vp, vp]
+    L.rt_unpack_tiles_device.argtypes = [vp, vp, u32, C.c_uint64, u32, u32, vp, vp]
     L.rt_primary_hits.argtypes = [vp, C.POINTER(Camera), u32, u32, vp]
     L.rt_primary_hits_device.argtypes = [vp, C.POINTER(Camera), u32, u32, vp, vp]
     L.rt_intersect.argtypes = [vp, vp, u32, vp]
@@ -222,6 +230,13 @@ class Context:
             tile = (0, 0, width, height)
         self._check(self._L.rt_resolve_device(self._h, d_sums, width, height, spp_div, flags, *tile, d_rgb, stream))
 
+    def pack_tiles_device(self, d_sums, width, height, spp_div, tile_first, tile_stride, d_tiles, stream=None, flags=0):
+        self._check(self._L.rt_pack_tiles_device(self._h, d_sums, width, height, spp_div, flags, tile_first,
+                                                 tile_stride, d_tiles, stream))
+
+    def unpack_tiles_device(self, d_blocks, n_blocks, block_bytes, width, height, d_rgb, stream=None):
+        self._check(self._L.rt_unpack_tiles_device(self._h, d_blocks, n_blocks, block_bytes, width, height, d_rgb, stream))
+
     def render_progressive(self, cam, p, samples_per_pass, on_pass=None, tile=None, rgb=None, fill=255):
         """on_pass(samples_done, samples_total, rgb) -> truthy to stop."""
         if tile is None:
@@ -257,3 +272,8 @@ class Context:
 
     def reset_stats(self):
         self._check(self._L.rt_reset_stats(self._h))
+
+
+def tile_block_bytes(width, height, tile_first, tile_stride):
+    """Bytes of the block rt_pack_tiles_device writes for the tiles first, first + stride, ..."""
+    return int(load().rt_tile_block_bytes(width, height, tile_first, tile_stride))

@@ -24,14 +24,14 @@ def test_library_exports_every_declared_symbol():
     lib = rtamd.load()
     for name in declared_symbols():
         assert getattr(lib, name) is not None, name
-    assert lib.rt_abi_version() == 1
+    assert lib.rt_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     assert rtamd.SPHERE_DTYPE.itemsize == 36  # class Sphere, Source/main.cpp:362-391
     assert C.sizeof(rtamd.Camera) == 48
     assert C.sizeof(rtamd.Params) == 48
-    assert C.sizeof(rtamd.Stats) == 40
+    assert C.sizeof(rtamd.Stats) == 64
 
 
 def test_status_strings():

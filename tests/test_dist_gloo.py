@@ -41,6 +41,30 @@ class OracleTracer:
         q = sums.numpy().view(np.uint32) // spp
         rgb.numpy()[:] = np.minimum(q, 255).astype(np.uint8)
 
+    def pack_tiles(self, sums, width, height, spp, first, stride, block):
+        """Tile-major block of the tiles first, first + stride, ...: 192 bytes each, (ly*8 + lx)*3."""
+        q = np.minimum(sums.numpy().view(np.uint32).reshape(height, width, 3) // spp, 255).astype(np.uint8)
+        tiles_x, tiles_y = (width + 7) // 8, (height + 7) // 8
+        out = block.numpy()
+        out[:] = 0
+        for k, t in enumerate(range(first, tiles_x * tiles_y, stride)):
+            ty, tx = divmod(t, tiles_x)
+            tile = np.zeros((8, 8, 3), dtype=np.uint8)
+            part = q[ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8]
+            tile[:part.shape[0], :part.shape[1]] = part
+            out[k * 192:(k + 1) * 192] = tile.reshape(-1)
+
+    def unpack_tiles(self, blocks, n_blocks, block_bytes, width, height, rgb):
+        img = rgb.numpy().reshape(height, width, 3)
+        tiles_x, tiles_y = (width + 7) // 8, (height + 7) // 8
+        src = blocks.numpy()
+        for t in range(tiles_x * tiles_y):
+            ty, tx = divmod(t, tiles_x)
+            b, k = t % n_blocks, t // n_blocks
+            tile = src[b * block_bytes + k * 192:b * block_bytes + (k + 1) * 192].reshape(8, 8, 3)
+            h, w = min(8, height - ty * 8), min(8, width - tx * 8)
+            img[ty * 8:ty * 8 + h, tx * 8:tx * 8 + w] = tile[:h, :w]
+
 
 def _worker(rank, world, port, partition, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -54,8 +78,16 @@ def _worker(rank, world, port, partition, out_path):
     for _ in range(2):  # twice: the frame must not depend on what the buffers held
         dist_render.trace_frame(tracer, p, sums, rgb, rank, world, dist)
     dist.barrier()
+    # the pipelined form: three frames through two rotating slots, exchange of one overlapping the next
+    pipe = dist_render.FramePipeline(tracer, p, (W, H, SPP), partition, rank, world, dist, torch, "cpu", slots=2)
+    for _ in range(3):
+        pipe.submit()
+    last = pipe.finish()
+    dist.barrier()
     if rank == 0:
         np.save(out_path, rgb.numpy().reshape(H, W, 3))
+        np.save(out_path + ".pipe.npy", torch.stack(pipe.rgb).numpy().reshape(2, H, W, 3))
+        assert last == 0
     dist.destroy_process_group()
 
 
@@ -74,6 +106,17 @@ def test_two_rank_frame_equals_single_process_frame(tmp_path, partition):
     got = np.load(out)
     want, _, _ = O.trace_tile(O.default_scene(), O.default_camera(), W, H, SPP, DEPTH, O.RNG_COUNTER, seed=SEED)
     assert np.array_equal(got, want)
+    piped = np.load(out + ".pipe.npy")
+    assert np.array_equal(piped[0], want) and np.array_equal(piped[1], want)
+
+
+def test_tile_blocks_cover_every_tile_once():
+    for w, h in ((40, 26), (8, 8), (1, 1), (1920, 1080), (61, 43)):
+        n = ((w + 7) // 8) * ((h + 7) // 8)
+        for world in (1, 2, 3, 8):
+            sizes = [dist_render.tile_block_bytes(w, h, r, world) for r in range(world)]
+            assert sum(sizes) == 192 * n and max(sizes) == sizes[0]
+            assert sizes == [rtamd.tile_block_bytes(w, h, r, world) for r in range(world)]
 
 
 def test_sample_slices_cover_the_range_exactly():

@@ -33,12 +33,22 @@ def _worker(rank, world, port, partition, out_path):
     p = dist_render.rank_params(W, H, SPP, DEPTH, SEED, partition, rank, world)
     sums = torch.zeros(W * H * 3, dtype=torch.int32, device="cuda")
     rgb = torch.zeros(W * H * 3, dtype=torch.uint8, device="cuda")
+    # gloo moves host tensors: the exchanged buffers are staged through the host here (over RCCL,
+    # one device per rank, they stay on the devices)
     for _ in range(2):
-        dist_render.trace_frame(tracer, p, sums, rgb, rank, world, dist)
+        dist_render.trace_frame(tracer, p, sums, rgb, rank, world, dist, host_exchange=True)
+    torch.cuda.synchronize()
+    dist.barrier()
+    pipe = dist_render.FramePipeline(tracer, p, (W, H, SPP), partition, rank, world, dist, torch, "cuda", slots=2,
+                                     host_exchange=True)
+    for _ in range(3):
+        pipe.submit()
+    pipe.finish()
     torch.cuda.synchronize()
     dist.barrier()
     if rank == 0:
         np.save(out_path, rgb.cpu().numpy().reshape(H, W, 3))
+        np.save(out_path + ".pipe.npy", torch.stack(pipe.rgb).cpu().numpy().reshape(2, H, W, 3))
     ctx.close()
     dist.destroy_process_group()
 
@@ -61,3 +71,5 @@ def test_two_processes_on_the_device_assemble_the_oracle_frame(tmp_path, partiti
     sc = scenes.random_spheres(500)
     want, _, _ = O.trace_tile(sc, O.camera(*scenes.RANDOM_SPHERES_CAMERA), W, H, SPP, DEPTH, O.RNG_COUNTER, seed=SEED)
     assert np.array_equal(got, want)
+    piped = np.load(out + ".pipe.npy")
+    assert np.array_equal(piped[0], want) and np.array_equal(piped[1], want)

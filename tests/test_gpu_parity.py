@@ -459,6 +459,44 @@ def test_random_calls_do_not_depend_on_how_the_queue_cuts_them(ctx, torch):
         ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
 
 
+def test_executed_work_counters(ctx):
+    """RT_OPT_COUNT_WORK: the counting build gives the same frame and ray count, and tallies what
+    the scan executed -- every test for the reference's own loop, a few per cent of them for the
+    hierarchy; without the option the tallies stay 0."""
+    sc = c3_scene()
+    ctx.set_scene(sc)
+    cam, p = rtamd.make_camera(*C3_CAM), rtamd.params(160, 90, 4, 8, seed=9)
+    want, _, rays = O.trace_tile(sc, O.camera(*C3_CAM), 160, 90, 4, 8, O.RNG_COUNTER, seed=9)
+    seen = {}
+    try:
+        for filt in (rtamd.FILTER_EXACT, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX, rtamd.FILTER_BVH):
+            ctx.set_option(rtamd.OPT_FILTER, filt)
+            ctx.set_option(rtamd.OPT_COUNT_WORK, 1)
+            ctx.reset_stats()
+            got = ctx.render(cam, p)
+            st = ctx.stats()
+            assert np.array_equal(got, want) and st.rays == rays
+            assert st.sphere_tests == rays * len(sc)
+            seen[filt] = (st.node_visits, st.exact_tests, st.root_evaluations)
+            ctx.set_option(rtamd.OPT_COUNT_WORK, 0)
+            ctx.reset_stats()
+            ctx.render(cam, p)
+            st = ctx.stats()
+            assert (st.node_visits, st.exact_tests, st.root_evaluations) == (0, 0, 0) and st.rays == rays
+    finally:
+        ctx.set_option(rtamd.OPT_COUNT_WORK, 0)
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
+    nodes, exact, roots = seen[rtamd.FILTER_EXACT]
+    assert nodes == 0 and exact == rays * len(sc)       # the reference's loop: every sphere, every ray
+    assert 0 < roots < exact // 50                       # few discriminants are non-negative
+    for filt in (rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX):
+        n2, e2, r2 = seen[filt]
+        # the conservative filters pass a superset of the non-negative discriminants, slightly larger
+        assert n2 == 0 and roots <= r2 <= e2 < roots * 1.05 + 64
+    nb, eb, rb = seen[rtamd.FILTER_BVH]
+    assert nb > rays and eb < exact // 20 and rb <= eb
+
+
 def test_edge_cases(ctx):
     cam = rtamd.default_camera()
     # empty scene: every ray is sky
