@@ -1,34 +1,45 @@
-// multi_gpu_rccl.cpp -- one frame over all GPUs of a node from a C++ host, without Python:
-// one rt_context per device, the frame's samples sliced over the devices, the per-pixel integer
-// sums reduced to device 0 with RCCL (ncclReduce over xGMI), device 0 divides and packs the frame.
-// This is the C++ twin of ray-tracer_amd/python/dist_render.py (which runs one process per GPU);
-// the frame is bit-identical to the single-GPU one for any number of devices.
+// multi_gpu_rccl.cpp -- one frame over the GPUs of a node from a C++ host, through rt_multi_*:
+// the reference's TraceScene (Source/main.cpp:647-659) with devices in place of its four threads.
+// The library splits the frame (sample slices, reduced with ncclReduce; or interleaved 8x8 tiles,
+// gathered with ncclSend/ncclRecv), runs every device from this one thread and assembles the
+// picture on the first device; the frame is bit-identical to the single-GPU one.
 //
-//   hipcc -O2 -std=c++17 -I include examples/multi_gpu_rccl.cpp -L ray-tracer_amd -lrt_mi355x -lrccl \
-//         -Wl,-rpath,$PWD/ray-tracer_amd -o multi_gpu_rccl && ./multi_gpu_rccl [n_gpus] [out.ppm]
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
-
+//   make -C examples     (g++ -std=c++17 -I include ... -L ray-tracer_amd -lrt_mi355x)
+//   ./multi_gpu_rccl [n_gpus] [samples|tiles] [rccl|peer] [out.ppm]
+//
+// n_gpus larger than the node's device count reuses devices round robin (ranks that share a device
+// exchange by device-local copies), which is how this runs on a one-GPU machine.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "rt_mi355x.h"
 
-#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-#define CHECK_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { std::fprintf(stderr, "%s: %s\n", #x, ncclGetErrorString(r_)); return 1; } } while (0)
-#define CHECK_RT(ctx, x) do { int s_ = (x); if (s_ != RT_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #x, rt_status_string(s_), rt_last_error(ctx)); return 1; } } while (0)
+#define CHECK_RT(x) do { int s_ = (x); if (s_ != RT_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #x, rt_status_string(s_), rt_multi_last_error(multi)); return 1; } } while (0)
 
 int main(int argc, char **argv)
 {
-    int n_dev = 0;
-    CHECK_HIP(hipGetDeviceCount(&n_dev));
-    if (argc > 1 && std::atoi(argv[1]) > 0 && std::atoi(argv[1]) < n_dev)
-        n_dev = std::atoi(argv[1]);
-    if (n_dev < 1) { std::fprintf(stderr, "no HIP device\n"); return 1; }
+    const int n_ranks = argc > 1 && std::atoi(argv[1]) > 0 ? std::atoi(argv[1]) : 1;
+    const int partition = argc > 2 && std::strcmp(argv[2], "tiles") == 0 ? RT_PARTITION_TILES : RT_PARTITION_SAMPLES;
+    const int exchange = argc > 3 && std::strcmp(argv[3], "peer") == 0 ? RT_EXCHANGE_PEER_COPY
+                       : argc > 3 && std::strcmp(argv[3], "rccl") == 0 ? RT_EXCHANGE_RCCL : RT_EXCHANGE_AUTO;
 
-    // the reference's scene and camera (Source/main.cpp:520-526, 605-608), 1080p, 64 spp per GPU
+    // how many devices are there?  rt_create fails with RT_ERR_INVALID_ARGUMENT past the last one
+    int n_dev = 0;
+    for (rt_context *probe = nullptr; n_dev < 64 && rt_create(n_dev, &probe) == RT_OK; ++n_dev)
+        rt_destroy(probe);
+    if (n_dev == 0) { std::fprintf(stderr, "no HIP device\n"); return 1; }
+    std::vector<int> ids(n_ranks);
+    for (int i = 0; i < n_ranks; ++i) ids[i] = i % n_dev;
+
+    rt_multi *multi = nullptr;
+    const int st = rt_multi_create(ids.data(), (uint32_t)n_ranks, exchange, &multi);
+    if (st != RT_OK) { std::fprintf(stderr, "rt_multi_create: %s\n", rt_status_string(st)); return 1; }
+
+    // the reference's scene and camera (Source/main.cpp:520-526, 605-608) at 1080p, 64 spp
     const rt_sphere spheres[4] = {
         { { -1.0f, 0.0f, -1.0f }, { 0.8f, 0.6f, 0.2f }, 0.5f, RT_MAT_METAL, 0.65f },
         { { 0.0f, 0.0f, -1.0f }, { 255.0f, 0.0f, 0.0f }, 0.5f, RT_MAT_DIFFUSE, 0.0f },
@@ -38,85 +49,34 @@ int main(int argc, char **argv)
     const float from[3] = { 0, 0, 0 }, at[3] = { 0, 0, -1 }, up[3] = { 0, 1, 0 };
     rt_camera cam;
     rt_camera_init(from, at, up, 90.0f, &cam);
-    const uint32_t W = 1920, H = 1080, spp_per_gpu = 64, spp = spp_per_gpu * (uint32_t)n_dev;
-    const size_t n_sums = (size_t)W * H * 3;
+    CHECK_RT(rt_multi_set_scene(multi, spheres, 4));
+    rt_params p;
+    std::memset(&p, 0, sizeof p);
+    p.width = 1920; p.height = 1080; p.spp = 64; p.max_depth = 10; p.seed = 1;
+    std::vector<uint8_t> rgb((size_t)p.width * p.height * 3);
 
-    std::vector<int> devs(n_dev);
-    for (int d = 0; d < n_dev; ++d) devs[d] = d;
-    std::vector<ncclComm_t> comms(n_dev);
-    CHECK_NCCL(ncclCommInitAll(comms.data(), n_dev, devs.data()));
+    CHECK_RT(rt_multi_render(multi, &cam, &p, partition, rgb.data())); // warm-up
+    CHECK_RT(rt_multi_reset_stats(multi));
+    const auto t0 = std::chrono::steady_clock::now();
+    CHECK_RT(rt_multi_render(multi, &cam, &p, partition, rgb.data()));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    rt_stats stats;
+    CHECK_RT(rt_multi_get_stats(multi, &stats));
+    unsigned long long h = 0xcbf29ce484222325ull; // FNV-1a-64 of the frame, to compare runs
+    for (uint8_t b : rgb) h = (h ^ b) * 0x100000001b3ull;
+    std::printf("%d rank(s) on %d device(s), %s, %s: %ux%u, %u spp, %llu rays, %.2f ms host wall -> %.0f Mrays/s, frame fnv %016llx\n",
+                n_ranks, n_ranks < n_dev ? n_ranks : n_dev, partition == RT_PARTITION_TILES ? "tiles gathered" : "sample slices reduced",
+                rt_multi_uses_rccl(multi) ? "RCCL" : "peer copies", p.width, p.height, p.spp,
+                (unsigned long long)stats.rays, ms, stats.rays / (ms * 1e-3) / 1e6, h);
 
-    std::vector<rt_context *> ctx(n_dev, nullptr);
-    std::vector<hipStream_t> stream(n_dev);
-    std::vector<uint32_t *> sums(n_dev, nullptr);
-    for (int d = 0; d < n_dev; ++d) {
-        CHECK_HIP(hipSetDevice(d));
-        CHECK_RT(nullptr, rt_create(d, &ctx[d]));
-        CHECK_RT(ctx[d], rt_set_scene(ctx[d], spheres, 4));
-        CHECK_HIP(hipStreamCreate(&stream[d]));
-        CHECK_HIP(hipMalloc((void **)&sums[d], n_sums * sizeof(uint32_t)));
-    }
-
-    hipEvent_t t0, t1;
-    CHECK_HIP(hipSetDevice(0));
-    CHECK_HIP(hipEventCreate(&t0));
-    CHECK_HIP(hipEventCreate(&t1));
-    uint8_t *d_rgb = nullptr;
-    CHECK_HIP(hipMalloc((void **)&d_rgb, n_sums));
-
-    for (int frame = 0; frame < 2; ++frame) { // the second frame is the timed one
-        CHECK_HIP(hipSetDevice(0));
-        CHECK_HIP(hipEventRecord(t0, stream[0]));
-        for (int d = 0; d < n_dev; ++d) { // trace: every device its slice of the samples
-            CHECK_HIP(hipSetDevice(d));
-            CHECK_HIP(hipMemsetAsync(sums[d], 0, n_sums * sizeof(uint32_t), stream[d]));
-            rt_params p;
-            std::memset(&p, 0, sizeof p);
-            p.width = W; p.height = H; p.spp = spp; p.max_depth = 10; p.seed = 1;
-            p.sample_begin = (uint32_t)d * spp_per_gpu;
-            p.sample_count = spp_per_gpu;
-            CHECK_RT(ctx[d], rt_accumulate_device(ctx[d], &cam, &p, 0, 0, (int)W, (int)H, sums[d], stream[d]));
-        }
-        CHECK_NCCL(ncclGroupStart()); // the frame's only exchange: integer sums to device 0
-        for (int d = 0; d < n_dev; ++d)
-            CHECK_NCCL(ncclReduce(sums[d], sums[d], n_sums, ncclUint32, ncclSum, 0, comms[d], stream[d]));
-        CHECK_NCCL(ncclGroupEnd());
-        CHECK_HIP(hipSetDevice(0));
-        CHECK_RT(ctx[0], rt_resolve_device(ctx[0], sums[0], W, H, spp, 0u, 0, 0, (int)W, (int)H, d_rgb, stream[0]));
-        CHECK_HIP(hipEventRecord(t1, stream[0]));
-        for (int d = 0; d < n_dev; ++d) {
-            CHECK_HIP(hipSetDevice(d));
-            CHECK_HIP(hipStreamSynchronize(stream[d]));
-        }
-    }
-    float ms = 0.f;
-    CHECK_HIP(hipEventElapsedTime(&ms, t0, t1));
-    unsigned long long rays = 0;
-    for (int d = 0; d < n_dev; ++d) {
-        rt_stats st;
-        CHECK_RT(ctx[d], rt_get_stats(ctx[d], &st));
-        rays += st.rays / 2; // two frames were traced
-    }
-    std::printf("%d GPU(s): %ux%u, %u spp, %llu rays, %.2f ms on device 0's clock -> %.0f Mrays/s\n", n_dev, W, H, spp, rays,
-                ms, rays / (ms * 1e-3) / 1e6);
-
-    if (argc > 2) {
-        std::vector<uint8_t> rgb(n_sums);
-        CHECK_HIP(hipSetDevice(0));
-        CHECK_HIP(hipMemcpy(rgb.data(), d_rgb, n_sums, hipMemcpyDeviceToHost));
-        if (FILE *f = std::fopen(argv[2], "wb")) {
-            std::fprintf(f, "P6\n%u %u\n255\n", W, H);
-            for (uint32_t y = 0; y < H; ++y) // row 0 is the bottom of the picture
-                std::fwrite(rgb.data() + (size_t)(H - 1 - y) * W * 3, 1, (size_t)W * 3, f);
+    if (argc > 4) {
+        if (FILE *f = std::fopen(argv[4], "wb")) {
+            std::fprintf(f, "P6\n%u %u\n255\n", p.width, p.height);
+            for (uint32_t y = 0; y < p.height; ++y) // row 0 is the bottom of the picture
+                std::fwrite(rgb.data() + (size_t)(p.height - 1 - y) * p.width * 3, 1, (size_t)p.width * 3, f);
             std::fclose(f);
         }
     }
-    for (int d = 0; d < n_dev; ++d) {
-        CHECK_HIP(hipSetDevice(d));
-        (void)hipFree(sums[d]);
-        (void)hipStreamDestroy(stream[d]);
-        rt_destroy(ctx[d]);
-        ncclCommDestroy(comms[d]);
-    }
+    rt_multi_destroy(multi);
     return 0;
 }

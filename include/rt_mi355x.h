@@ -227,6 +227,47 @@ int rt_primary_hits_device(rt_context *ctx, const rt_camera *cam, uint32_t width
  * float point[3], float normal[3]} (32 bytes, zero where there is no hit). */
 int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out);
 
+/* Several devices of one node, one host process ------------------------------ */
+
+/* TraceScene (Source/main.cpp:647-659) fans one frame out over THREAD_SPAWN_COUNT host threads, a
+ * column strip each.  An rt_multi fans it out over GPUs instead: it owns one rt_context per entry of
+ * `device_ids`, splits every frame over them, and assembles the picture on the FIRST device with one
+ * exchange step per frame:
+ *   RT_PARTITION_SAMPLES  device i traces samples [i*spp/n, (i+1)*spp/n) of every pixel into its own
+ *                         integer sums, which are sum-reduced to the first device (12 bytes per
+ *                         pixel), which divides and packs;
+ *   RT_PARTITION_TILES    device i traces all samples of the 8x8 tiles i, i + n, ..., divides and
+ *                         packs them, and the tile blocks are gathered (3/n bytes per pixel and device).
+ * The picture is bit-identical to rt_render's for any n and either partition.  `exchange` selects
+ * the transport: RT_EXCHANGE_RCCL (ncclReduce / grouped ncclSend+ncclRecv; librccl is loaded with
+ * dlopen by this call), RT_EXCHANGE_PEER_COPY (the first device adds the others' sums in place over
+ * xGMI peer access, tile blocks are copied device to device), RT_EXCHANGE_AUTO (RCCL if it loads
+ * and all ids are distinct, else peer copies).  The same id may appear several times (ranks sharing
+ * a device exchange by peer copies; meant for testing on one GPU).  At most 16 entries.
+ * Frames are double-buffered: rt_multi_render_device returns when the frame is enqueued, and the
+ * exchange of one frame runs beside the tracing of the next. */
+typedef struct rt_multi rt_multi;
+enum { RT_PARTITION_SAMPLES = 0, RT_PARTITION_TILES = 1 };
+enum { RT_EXCHANGE_AUTO = 0, RT_EXCHANGE_RCCL = 1, RT_EXCHANGE_PEER_COPY = 2 };
+
+int rt_multi_create(const int *device_ids, uint32_t n_devices, int exchange, rt_multi **multi);
+int rt_multi_destroy(rt_multi *multi);
+const char *rt_multi_last_error(const rt_multi *multi);
+uint32_t rt_multi_device_count(const rt_multi *multi);
+int rt_multi_uses_rccl(const rt_multi *multi);                   /* 1 if the exchange runs over RCCL */
+rt_context *rt_multi_context(rt_multi *multi, uint32_t index);   /* the index-th device's context (owned by multi) */
+int rt_multi_set_scene(rt_multi *multi, const rt_sphere *spheres, uint32_t n);   /* on every device */
+int rt_multi_set_option(rt_multi *multi, int option, int64_t value);             /* on every device */
+/* The whole frame (params->sample_* and tile_* must be 0) into host memory `rgb`; returns when it is there. */
+int rt_multi_render(rt_multi *multi, const rt_camera *cam, const rt_params *params, int partition, uint8_t *rgb);
+/* The same into `d_rgb`, memory of the FIRST device; only enqueues (frames complete in the order of the
+ * calls; rt_multi_synchronize waits for all of them). */
+int rt_multi_render_device(rt_multi *multi, const rt_camera *cam, const rt_params *params, int partition,
+                           uint8_t *d_rgb);
+int rt_multi_synchronize(rt_multi *multi);
+int rt_multi_get_stats(rt_multi *multi, rt_stats *stats);        /* counters summed over the devices */
+int rt_multi_reset_stats(rt_multi *multi);
+
 /* Tuning (no counterpart in the reference) ---------------------------------- */
 
 typedef enum rt_option {

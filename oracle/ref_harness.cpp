@@ -74,6 +74,20 @@ static const Camera* parse_camera(char** a)
 	return new Camera(glm::vec3(f[0], f[1], f[2]), glm::vec3(f[3], f[4], f[5]), glm::vec3(f[6], f[7], f[8]), f[9]);
 }
 
+// Ray count of the reference's own loops.  The reference keeps no counter, and its source is not
+// touched: the Makefile's second build of this file (_ref/ref_harness_count) adds gcc's
+// -finstrument-functions, which calls the two hooks below around every function of this
+// translation unit (also where a function was inlined); entries of IntersectSceneSpheres are the
+// rays (one per GetRayColor call with depth > 0, Source/main.cpp:562).
+#ifdef RT_COUNT_CALLS
+static unsigned long long g_IntersectCalls = 0;
+extern "C" __attribute__((no_instrument_function)) void __cyg_profile_func_enter(void* fn, void*)
+{
+	if (fn == (void*)&IntersectSceneSpheres) g_IntersectCalls++;
+}
+extern "C" __attribute__((no_instrument_function)) void __cyg_profile_func_exit(void*, void*) {}
+#endif
+
 [[noreturn]] static void done()
 {
 	fflush(stdout);
@@ -119,6 +133,9 @@ int main(int argc, char** argv)
 		double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 		size_t nbytes = (size_t)g_Width * g_Height * 3;
 		printf("c1 xsize %d fnv %016llx seconds %.3f\n", xsize, (unsigned long long)fnv1a64(g_PixelData, nbytes), sec);
+#ifdef RT_COUNT_CALLS
+		printf("rays %llu\n", g_IntersectCalls);
+#endif
 		if (argc > 3 && strcmp(argv[3], "-") != 0) write_file(argv[3], g_PixelData, nbytes);
 		done();
 	}

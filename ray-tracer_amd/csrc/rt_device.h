@@ -102,6 +102,15 @@ struct TilesArgs {
     size_t block_bytes;        // unpack: bytes between two devices' blocks
 };
 
+// dst[i] += src[0][i] + ... + src[n_src - 1][i]: the first device of a sample-sliced frame adds the
+// other devices' sums, read in place (peer access or the same device).
+struct AddArgs {
+    uint32_t *dst;
+    const uint32_t *src[15];
+    uint32_t n_src;
+    size_t count;
+};
+
 struct HitsArgs {
     const Geom *geom;          // conservative filter records, or null for the exact scan
     const Geom *exact;
@@ -143,6 +152,7 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream);
 hipError_t launch_pack_tiles(const TilesArgs &a, hipStream_t stream);
 hipError_t launch_unpack_tiles(const TilesArgs &a, hipStream_t stream);
+hipError_t launch_add_sums(const AddArgs &a, hipStream_t stream);
 hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream);
 hipError_t launch_intersect(const IntersectArgs &a, hipStream_t stream);
 // Resident workgroups per CU of the trace kernel at this LDS size.

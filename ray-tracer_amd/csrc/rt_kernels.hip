@@ -656,6 +656,28 @@ __global__ void __launch_bounds__(256) unpack_tiles_kernel(const TilesArgs a)
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
 }
 
+// FinalColor += ... over devices (Source/main.cpp:633-635 is the per-sample add): integer sums, so
+// the order of the operands does not matter.  HBM/xGMI-bound; four words per lane and step.
+__global__ void __launch_bounds__(256) add_sums_kernel(const AddArgs a)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t quads = a.count / 4u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += stride) {
+        uint4 v = reinterpret_cast<const uint4 *>(a.dst)[i];
+        for (uint32_t s = 0; s < a.n_src; ++s) {
+            const uint4 w = reinterpret_cast<const uint4 *>(a.src[s])[i];
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        reinterpret_cast<uint4 *>(a.dst)[i] = v;
+    }
+    for (size_t i = quads * 4u + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count; i += stride) {
+        uint32_t v = a.dst[i];
+        for (uint32_t s = 0; s < a.n_src; ++s)
+            v += a.src[s][i];
+        a.dst[i] = v;
+    }
+}
+
 // Deterministic primary-ray closest-hit map (jitter 0.5): one lane per pixel,
 // the whole workgroup walks the sphere tiles together.
 __global__ void __launch_bounds__(256) primary_hits_kernel(const HitsArgs a, uint32_t tile_cap)
@@ -788,6 +810,7 @@ size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth,
 
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream)
 {
+    (void)hipGetLastError(); // a failure of some earlier, unrelated runtime call is not this launch\'s
     const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
     const bool multi = a.filter != kFilterBvh && a.n > a.tile_cap;
     const dim3 grid(n_workgroups), block(kTraceThreads);
@@ -841,6 +864,7 @@ hipError_t trace_occupancy(int filter, size_t lds_bytes, int *workgroups_per_cu)
 
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream)
 {
+    (void)hipGetLastError(); // a failure of some earlier, unrelated runtime call is not this launch\'s
     const uint32_t total = (uint32_t)a.w * (uint32_t)a.h;
     if (total == 0u)
         return hipSuccess;
@@ -850,6 +874,7 @@ hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream)
 
 hipError_t launch_pack_tiles(const TilesArgs &a, hipStream_t stream)
 {
+    (void)hipGetLastError(); // a failure of some earlier, unrelated runtime call is not this launch\'s
     if (a.n_own == 0u)
         return hipSuccess;
     hipLaunchKernelGGL(pack_tiles_kernel, dim3((a.n_own * 64u + 255u) / 256u), dim3(256), 0, stream, a);
@@ -858,10 +883,22 @@ hipError_t launch_pack_tiles(const TilesArgs &a, hipStream_t stream)
 
 hipError_t launch_unpack_tiles(const TilesArgs &a, hipStream_t stream)
 {
+    (void)hipGetLastError(); // a failure of some earlier, unrelated runtime call is not this launch\'s
     const uint32_t n_tiles = a.tiles_x * a.tiles_y;
     if (n_tiles == 0u)
         return hipSuccess;
     hipLaunchKernelGGL(unpack_tiles_kernel, dim3((n_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_sums(const AddArgs &a, hipStream_t stream)
+{
+    (void)hipGetLastError(); // a failure of some earlier, unrelated runtime call is not this launch\'s
+    if (a.count == 0u || a.n_src == 0u)
+        return hipSuccess;
+    const size_t want = (a.count / 4u + 255u) / 256u;
+    const uint32_t blocks = (uint32_t)(want < 1u ? 1u : (want > 4096u ? 4096u : want));
+    hipLaunchKernelGGL(add_sums_kernel, dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -874,6 +911,7 @@ static uint32_t scan_tile_cap(uint32_t n)
 
 hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream)
 {
+    (void)hipGetLastError(); // a failure of some earlier, unrelated runtime call is not this launch\'s
     if (a.width == 0u || a.height == 0u)
         return hipSuccess;
     const uint32_t cap = scan_tile_cap(a.n);
@@ -885,6 +923,7 @@ hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream)
 
 hipError_t launch_intersect(const IntersectArgs &a, hipStream_t stream)
 {
+    (void)hipGetLastError(); // a failure of some earlier, unrelated runtime call is not this launch\'s
     if (a.n_rays == 0u)
         return hipSuccess;
     const uint32_t cap = scan_tile_cap(a.n);

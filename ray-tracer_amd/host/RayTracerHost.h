@@ -190,6 +190,49 @@ private:
     rt_context *m_Ctx = nullptr;
 };
 
+// TraceScene over several devices: the reference starts THREAD_SPAWN_COUNT threads on column strips
+// (Source/main.cpp:647-659); this starts the frame on every device of the list (rt_multi_*), by sample
+// slices or by interleaved tiles, and the picture is assembled on the first device.
+class MultiDeviceTracer {
+public:
+    explicit MultiDeviceTracer(const std::vector<int> &devices, int exchange = RT_EXCHANGE_AUTO)
+    {
+        const int st = rt_multi_create(devices.data(), (uint32_t)devices.size(), exchange, &m_Multi);
+        if (st != RT_OK)
+            throw std::runtime_error(std::string("rt_multi_create: ") + rt_status_string(st));
+    }
+    ~MultiDeviceTracer() { if (m_Multi) rt_multi_destroy(m_Multi); }
+    MultiDeviceTracer(const MultiDeviceTracer &) = delete;
+    MultiDeviceTracer &operator=(const MultiDeviceTracer &) = delete;
+
+    void TraceScene(RenderState &s, int partition = RT_PARTITION_TILES)
+    {
+        Check(rt_multi_set_scene(m_Multi, reinterpret_cast<const rt_sphere *>(s.Spheres.data()), (uint32_t)s.Spheres.size()));
+        rt_params p;
+        std::memset(&p, 0, sizeof p);
+        p.width = s.Width; p.height = s.Height; p.spp = (uint32_t)s.SPP; p.max_depth = s.RAY_DEPTH; p.seed = s.Seed;
+        p.flags = s.Flags;
+        if (s.PixelData.size() != (size_t)s.Width * s.Height * 3) s.AllocatePixels();
+        Check(rt_multi_render(m_Multi, &s.SceneCamera.Pod(), &p, partition, s.PixelData.data()));
+    }
+
+    rt_stats Stats()
+    {
+        rt_stats st;
+        Check(rt_multi_get_stats(m_Multi, &st));
+        return st;
+    }
+    bool UsesRccl() const { return rt_multi_uses_rccl(m_Multi) != 0; }
+
+private:
+    void Check(int st)
+    {
+        if (st != RT_OK)
+            throw std::runtime_error(std::string(rt_status_string(st)) + ": " + rt_multi_last_error(m_Multi));
+    }
+    rt_multi *m_Multi = nullptr;
+};
+
 // Binary PPM (P6), top row first: g_PixelData's row 0 is the BOTTOM of the picture
 // (Source/main.cpp:273-281 with the quad's UVs, :220-225), so rows are flipped on output.
 bool WritePPM(const std::string &path, const RenderState &s);

@@ -5,6 +5,7 @@
 //   rt_render_cli [--width W --height H --spp N --depth D --seed S]
 //                 [--scene spheres.bin] [--camera fx fy fz ax ay az ux uy uz fov]
 //                 [--out image.ppm] [--progressive SAMPLES_PER_PASS]
+//                 [--devices 0,1,2,... [--partition tiles|samples] [--exchange auto|rccl|peer]]
 //                 [--dielectric] [--gamma2] [--float-shading]   (extensions, off by default)
 // Defaults are the reference's shipped constants: 1024x576, 100 spp, depth 10,
 // its four spheres and its camera.
@@ -39,6 +40,8 @@ int main(int argc, char **argv)
     RenderState state;
     std::string out = "render.ppm";
     unsigned per_pass = 0;
+    std::vector<int> devices;
+    int partition = RT_PARTITION_TILES, exchange = RT_EXCHANGE_AUTO;
     try {
         for (int i = 1; i < argc; ++i) {
             const std::string a = argv[i];
@@ -50,6 +53,27 @@ int main(int argc, char **argv)
             else if (a == "--seed") { need(1); state.Seed = std::strtoull(argv[++i], nullptr, 0); }
             else if (a == "--out") { need(1); out = argv[++i]; }
             else if (a == "--progressive") { need(1); per_pass = (unsigned)std::atoi(argv[++i]); }
+            else if (a == "--devices") {
+                need(1);
+                for (const char *c = argv[++i]; *c;) {
+                    char *end = nullptr;
+                    devices.push_back((int)std::strtol(c, &end, 10));
+                    if (end == c) throw std::invalid_argument("--devices takes a comma-separated list of device ids");
+                    c = *end == ',' ? end + 1 : end;
+                }
+            }
+            else if (a == "--partition") {
+                need(1);
+                const std::string v = argv[++i];
+                if (v != "tiles" && v != "samples") throw std::invalid_argument("--partition takes tiles or samples");
+                partition = v == "tiles" ? RT_PARTITION_TILES : RT_PARTITION_SAMPLES;
+            }
+            else if (a == "--exchange") {
+                need(1);
+                const std::string v = argv[++i];
+                if (v != "auto" && v != "rccl" && v != "peer") throw std::invalid_argument("--exchange takes auto, rccl or peer");
+                exchange = v == "rccl" ? RT_EXCHANGE_RCCL : v == "peer" ? RT_EXCHANGE_PEER_COPY : RT_EXCHANGE_AUTO;
+            }
             else if (a == "--dielectric") state.Flags |= RT_FLAG_DIELECTRIC;
             else if (a == "--gamma2") state.Flags |= RT_FLAG_GAMMA2;
             else if (a == "--float-shading") state.Flags |= RT_FLAG_FLOAT_SHADING;
@@ -71,8 +95,28 @@ int main(int argc, char **argv)
             }
         }
 
-        DeviceTracer tracer(0);
         state.AllocatePixels();
+        if (!devices.empty()) { // the frame over several devices, assembled on the first
+            if (per_pass > 0) throw std::invalid_argument("--progressive renders on one device");
+            MultiDeviceTracer multi(devices, exchange);
+            std::cout << std::endl << "Writing Pixel Data.." << std::endl;
+            std::cout << "Ray Tracing.." << std::endl;
+            const auto t0 = std::chrono::steady_clock::now();
+            multi.TraceScene(state, partition);
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const rt_stats st = multi.Stats();
+            std::printf("%ux%u, %d spp, depth %d, %zu spheres on %zu rank(s), %s, %s: %llu rays in %.3f s (%.1f Mrays/s)\n",
+                        state.Width, state.Height, state.SPP, state.RAY_DEPTH, state.Spheres.size(), devices.size(),
+                        partition == RT_PARTITION_TILES ? "tiles gathered" : "sample slices reduced",
+                        multi.UsesRccl() ? "RCCL" : "peer copies", (unsigned long long)st.rays, sec, st.rays / sec / 1e6);
+            if (!WritePPM(out, state)) {
+                std::fprintf(stderr, "cannot write %s\n", out.c_str());
+                return 2;
+            }
+            std::printf("wrote %s\n", out.c_str());
+            return 0;
+        }
+        DeviceTracer tracer(0);
         std::cout << std::endl << "Writing Pixel Data.." << std::endl; // Source/main.cpp:663-664
         std::cout << "Ray Tracing.." << std::endl;
         const auto t0 = std::chrono::steady_clock::now();

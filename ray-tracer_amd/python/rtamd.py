@@ -29,6 +29,9 @@ FILTER_AUTO, FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX, FILTER_BVH = -1, 
 EXPORTS = [
     "rt_abi_version", "rt_status_string", "rt_last_error", "rt_create", "rt_destroy", "rt_set_scene",
     "rt_camera_init", "rt_render", "rt_render_progressive", "rt_render_device", "rt_render_device_static", "rt_accumulate_device", "rt_resolve_device",
+    "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_device_count", "rt_multi_uses_rccl",
+    "rt_multi_context", "rt_multi_set_scene", "rt_multi_set_option", "rt_multi_render", "rt_multi_render_device",
+    "rt_multi_synchronize", "rt_multi_get_stats", "rt_multi_reset_stats",
     "rt_tile_block_bytes", "rt_pack_tiles_device", "rt_unpack_tiles_device", "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_accel_selfcheck", "rt_get_stats", "rt_reset_stats",
 ]
 
@@ -116,6 +119,22 @@ def load():
     L.rt_tile_block_bytes.restype = C.c_uint64
     L.rt_pack_tiles_device.argtypes = [vp, vp, u32, u32, u32, u32, u32, u32, vp, vp]
     L.rt_unpack_tiles_device.argtypes = [vp, vp, u32, C.c_uint64, u32, u32, vp, vp]
+    L.rt_multi_create.argtypes = [C.POINTER(C.c_int), u32, i, C.POINTER(vp)]
+    L.rt_multi_destroy.argtypes = [vp]
+    L.rt_multi_last_error.argtypes = [vp]
+    L.rt_multi_last_error.restype = C.c_char_p
+    L.rt_multi_device_count.argtypes = [vp]
+    L.rt_multi_device_count.restype = u32
+    L.rt_multi_uses_rccl.argtypes = [vp]
+    L.rt_multi_context.argtypes = [vp, u32]
+    L.rt_multi_context.restype = vp
+    L.rt_multi_set_scene.argtypes = [vp, vp, u32]
+    L.rt_multi_set_option.argtypes = [vp, i, C.c_int64]
+    L.rt_multi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, vp]
+    L.rt_multi_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, vp]
+    L.rt_multi_synchronize.argtypes = [vp]
+    L.rt_multi_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rt_multi_reset_stats.argtypes = [vp]
     L.rt_primary_hits.argtypes = [vp, C.POINTER(Camera), u32, u32, vp]
     L.rt_primary_hits_device.argtypes = [vp, C.POINTER(Camera), u32, u32, vp, vp]
     L.rt_intersect.argtypes = [vp, vp, u32, vp]
@@ -277,3 +296,64 @@ class Context:
 def tile_block_bytes(width, height, tile_first, tile_stride):
     """Bytes of the block rt_pack_tiles_device writes for the tiles first, first + stride, ..."""
     return int(load().rt_tile_block_bytes(width, height, tile_first, tile_stride))
+
+
+PARTITION_SAMPLES, PARTITION_TILES = 0, 1
+EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_PEER_COPY = 0, 1, 2
+
+
+class Multi:
+    """One rt_multi: several devices (or several ranks on one device) driven from this process."""
+
+    def __init__(self, device_ids, exchange=EXCHANGE_AUTO):
+        self._L = load()
+        self._h = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        st = self._L.rt_multi_create(ids, len(device_ids), exchange, C.byref(self._h))
+        if st != 0:
+            raise RtError(f"rt_multi_create({list(device_ids)}): {self._L.rt_status_string(st).decode()}")
+
+    def close(self):
+        if self._h:
+            self._L.rt_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            raise RtError(f"{self._L.rt_status_string(st).decode()}: {self._L.rt_multi_last_error(self._h).decode()}")
+
+    @property
+    def uses_rccl(self):
+        return bool(self._L.rt_multi_uses_rccl(self._h))
+
+    def set_scene(self, spheres):
+        spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        self._check(self._L.rt_multi_set_scene(self._h, spheres.ctypes.data if len(spheres) else None, len(spheres)))
+
+    def set_option(self, option, value):
+        self._check(self._L.rt_multi_set_option(self._h, option, value))
+
+    def render(self, cam, p, partition):
+        rgb = np.zeros((p.height, p.width, 3), dtype=np.uint8)
+        self._check(self._L.rt_multi_render(self._h, C.byref(cam), C.byref(p), partition, rgb.ctypes.data))
+        return rgb
+
+    def render_device(self, cam, p, partition, d_rgb):
+        self._check(self._L.rt_multi_render_device(self._h, C.byref(cam), C.byref(p), partition, d_rgb))
+
+    def synchronize(self):
+        self._check(self._L.rt_multi_synchronize(self._h))
+
+    def stats(self):
+        s = Stats()
+        self._check(self._L.rt_multi_get_stats(self._h, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._check(self._L.rt_multi_reset_stats(self._h))

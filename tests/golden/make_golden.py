@@ -2,6 +2,7 @@
 
 Run in the build container only (it needs /root/reference to build the harness):
     make -C oracle && python tests/golden/make_golden.py
+    python tests/golden/make_golden.py rays      # only re-count the rays of the shipped frame
 Every fixture is data: inputs and the outputs the reference's own code produced.
 """
 import json
@@ -30,6 +31,16 @@ def fnv1a64(b):
     for x in bytes(b):
         h = ((h ^ x) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
     return h
+
+
+def ray_counts(kat):
+    """IntersectSceneSpheres calls of TraceThreadFunction(0, 0, xsize, 576), counted by the build of
+    the harness that hooks function entries (the reference reports no count itself); the picture
+    of that build must be the uninstrumented one's."""
+    for key, xsize in (("c1_strip32", 32), ("c1_full", 1024)):
+        out = subprocess.check_output([HARNESS + "_count", "c1", str(xsize), "-"], text=True)
+        assert re.search(r"fnv ([0-9a-f]+)", out).group(1) == kat[key + "_fnv"]
+        kat[key + "_rays"] = int(re.search(r"rays (\d+)", out).group(1))
 
 
 def cam_args(cam):
@@ -67,6 +78,8 @@ def main():
     assert kat["c1_full_fnv"] == "%016x" % fnv1a64(img.tobytes())
     # rows 280..295 of the full frame (sphere silhouettes + horizon), all columns
     np.save(os.path.join(HERE, "c1_full_rows280_296.npy"), np.ascontiguousarray(img[280:296]))
+
+    ray_counts(kat)
 
     # ---- deterministic primary hit maps, 1920x1080
     f = os.path.join(tmp, "c2.i32")
@@ -135,4 +148,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["rays"]:
+        path = os.path.join(HERE, "kat.json")
+        kat = json.load(open(path))
+        ray_counts(kat)
+        with open(path, "w") as fp:
+            json.dump(kat, fp, indent=1, sort_keys=True)
+        print({k: v for k, v in kat.items() if k.endswith("_rays")})
+    else:
+        main()

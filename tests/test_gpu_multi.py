@@ -1,0 +1,131 @@
+"""rt_multi_*: one frame over several devices from one host process (the reference's TraceScene,
+Source/main.cpp:647-659, with devices in place of its four threads).  A one-GPU machine runs it with
+one device (the RCCL calls execute with a single rank) and with several logical ranks sharing the
+device (peer-copy exchange): every split, buffer rotation and exchange step except RCCL between
+distinct devices.  The assembled frame must be the single-context frame, bit for bit."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle_lib as O
+import rtamd
+import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+C3_CAM = scenes.RANDOM_SPHERES_CAMERA
+
+
+def c3_scene():
+    return np.fromfile(os.path.join(G, "scene_c3_500.bin"), dtype=rtamd.SPHERE_DTYPE)
+
+
+@pytest.mark.parametrize("ids,exchange", [([0], rtamd.EXCHANGE_RCCL), ([0], rtamd.EXCHANGE_PEER_COPY),
+                                          ([0, 0], rtamd.EXCHANGE_AUTO), ([0, 0, 0], rtamd.EXCHANGE_PEER_COPY),
+                                          ([0] * 8, rtamd.EXCHANGE_AUTO)])
+@pytest.mark.parametrize("partition", [rtamd.PARTITION_SAMPLES, rtamd.PARTITION_TILES])
+def test_multi_frame_equals_oracle_frame(ids, exchange, partition):
+    sc = c3_scene()
+    W, H, SPP, D = 100, 61, 6, 8  # ragged tiles; 6 samples over 8 ranks leaves two ranks without any
+    want, _, rays = O.trace_tile(sc, O.camera(*C3_CAM), W, H, SPP, D, O.RNG_COUNTER, seed=4)
+    m = rtamd.Multi(ids, exchange)
+    try:
+        assert m.uses_rccl == (exchange == rtamd.EXCHANGE_RCCL)  # duplicate ids and PEER_COPY never use RCCL
+        m.set_scene(sc)
+        cam, p = rtamd.make_camera(*C3_CAM), rtamd.params(W, H, SPP, D, seed=4)
+        for _ in range(3):  # both buffer slots, and the first one again
+            m.reset_stats()
+            got = m.render(cam, p, partition)
+            assert np.array_equal(got, want)
+            assert m.stats().rays == rays
+    finally:
+        m.close()
+
+
+def test_multi_pipelined_frames_on_device(tmp_path):
+    """Frames enqueued back to back without waiting: slots rotate, each frame lands in its buffer."""
+    import torch
+
+    sc = c3_scene()
+    W, H, D = 256, 144, 8
+    cam = rtamd.make_camera(*C3_CAM)
+    ctx = rtamd.Context(0)
+    ctx.set_scene(sc)
+    frames = [rtamd.params(W, H, 8, D, seed=s) for s in (1, 2, 3, 4, 5)]
+    want = [ctx.render(cam, p) for p in frames]
+    ctx.close()
+    for partition in (rtamd.PARTITION_SAMPLES, rtamd.PARTITION_TILES):
+        m = rtamd.Multi([0, 0, 0, 0])
+        try:
+            m.set_scene(sc)
+            outs = [torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda") for _ in frames]
+            torch.cuda.synchronize()
+            for p, o in zip(frames, outs):
+                m.render_device(cam, p, partition, o.data_ptr())
+            m.synchronize()
+            for o, w in zip(outs, want):
+                assert np.array_equal(o.cpu().numpy().reshape(H, W, 3), w)
+            # a larger frame afterwards: the buffers grow
+            big = rtamd.params(640, 360, 4, D, seed=9)
+            got = m.render(cam, big, partition)
+        finally:
+            m.close()
+        ctx = rtamd.Context(0)
+        ctx.set_scene(sc)
+        assert np.array_equal(got, ctx.render(cam, big))
+        ctx.close()
+
+
+def test_multi_full_size_frame_and_bad_arguments():
+    sc = c3_scene()
+    cam = rtamd.make_camera(*C3_CAM)
+    p = rtamd.params(1920, 1080, 16, 8, seed=1)
+    ctx = rtamd.Context(0)
+    ctx.set_scene(sc)
+    want = ctx.render(cam, p)
+    ctx.close()
+    m = rtamd.Multi([0, 0])
+    try:
+        m.set_scene(sc)
+        assert np.array_equal(m.render(cam, p, rtamd.PARTITION_TILES), want)
+        assert np.array_equal(m.render(cam, p, rtamd.PARTITION_SAMPLES), want)
+        L = rtamd.load()
+        buf = np.zeros((1080, 1920, 3), dtype=np.uint8)
+        sliced = rtamd.params(1920, 1080, 16, 8, seed=1, sample_begin=0, sample_count=4)
+        assert L.rt_multi_render(m._h, C.byref(cam), C.byref(sliced), 0, buf.ctypes.data) == -1
+        assert b"splits the frame itself" in L.rt_multi_last_error(m._h)
+        assert L.rt_multi_render(m._h, C.byref(cam), C.byref(p), 7, buf.ctypes.data) == -1
+        assert L.rt_multi_render(m._h, None, C.byref(p), 0, buf.ctypes.data) == -1
+    finally:
+        m.close()
+    h = C.c_void_p()
+    ids = (C.c_int * 2)(0, 0)
+    assert rtamd.load().rt_multi_create(ids, 2, rtamd.EXCHANGE_RCCL, C.byref(h)) == -1  # RCCL: one rank per device
+    assert rtamd.load().rt_multi_create(ids, 0, 0, C.byref(h)) == -1
+    assert rtamd.load().rt_multi_create((C.c_int * 1)(99), 1, 0, C.byref(h)) != 0
+
+
+def test_cpp_hosts_drive_several_ranks(tmp_path):
+    """examples/multi_gpu_rccl (plain C++ over rt_multi_*) and rt_render_cli --devices: same picture
+    for one rank over RCCL, and for three ranks sharing the device, either partition."""
+    exe = os.path.join(ROOT, "examples", "multi_gpu_rccl")
+    assert os.path.exists(exe), "run __graft_entry__.build() (make -C examples)"
+    lines = []
+    for args in (("1", "samples", "rccl"), ("1", "tiles", "rccl"), ("3", "samples", "peer"), ("3", "tiles", "auto")):
+        out = subprocess.run([exe, *args], check=True, capture_output=True, text=True, timeout=120).stdout
+        lines.append(out)
+    fnv = {line.split("frame fnv ")[1].strip() for line in lines}
+    assert len(fnv) == 1, lines
+    assert "RCCL" in lines[0] and "peer copies" in lines[2]
+    cli = os.path.join(ROOT, "ray-tracer_amd", "rt_render_cli")
+    one, many = str(tmp_path / "one.ppm"), str(tmp_path / "many.ppm")
+    base = ["--width", "160", "--height", "90", "--spp", "5", "--seed", "3"]
+    subprocess.run([cli, *base, "--out", one], check=True, capture_output=True, timeout=120)
+    text = subprocess.run([cli, *base, "--devices", "0,0,0", "--partition", "samples", "--out", many], check=True,
+                          capture_output=True, text=True, timeout=120).stdout
+    assert "3 rank(s)" in text and open(one, "rb").read() == open(many, "rb").read()

@@ -126,6 +126,18 @@ def test_c1_strip_pixel_exact():
     for k, v in KAT["c1_strip32_pixels"].items():
         x, y = map(int, k.split(","))
         assert rgb[y, x].tolist() == v
+    assert rays == KAT["c1_strip32_rays"]  # IntersectSceneSpheres calls counted in the reference's own run
+
+
+def test_c1_full_frame_pixel_exact():
+    """The shipped frame whole: TraceThreadFunction(0, 0, 1024, 576) on one thread from a fresh
+    generator (Source/main.cpp:613-645) -- every byte (hash of the reference's frame, 16 committed
+    rows) and the number of rays its loops traced.  About 25 s."""
+    rgb, _, rays = O.trace_tile(O.default_scene(), O.default_camera(), 1024, 576, 100, 10, O.RNG_MT19937)
+    assert "%016x" % O.fnv1a64(rgb) == KAT["c1_full_fnv"]
+    assert np.array_equal(rgb[280:296], np.load(os.path.join(G, "c1_full_rows280_296.npy")))
+    assert np.array_equal(rgb[:, :32], np.load(os.path.join(G, "c1_strip32.npy")))
+    assert rays == KAT["c1_full_rays"] == 160615330
 
 
 def test_c3_scene_sample_loop_pixel_exact():
