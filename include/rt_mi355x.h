@@ -310,6 +310,12 @@ int rt_accel_selfcheck(const rt_sphere *spheres, uint32_t n, int leaf_spheres, u
 /* Waits for the context's enqueued work, then reports. */
 int rt_get_stats(rt_context *ctx, rt_stats *stats);
 int rt_reset_stats(rt_context *ctx);
+/* Measurement aid of the counting build (RT_OPT_COUNT_WORK 1): for the first `n` (<= 12) sections of the
+ * trace kernel -- 0 wave pass, 1 refill, 2 walk start (always-tested spheres), 3 hierarchy node, 4 group of
+ * up to four leaf records, 5 root evaluation, 6 first random-point attempt, 7 helper attempt, 8 scatter,
+ * 9 replay of one recursion level, 10 walk set-up, 11 shading -- out[2i] = how many times a 64-lane wave
+ * executed the section and out[2i+1] = with how many lanes enabled in total, since the last reset. */
+int rt_get_work_profile(rt_context *ctx, uint64_t *out, uint32_t n);
 
 #ifdef __cplusplus
 }

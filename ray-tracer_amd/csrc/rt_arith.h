@@ -20,7 +20,23 @@ struct WorkCount {
     uint32_t nodes; // inner nodes of the hierarchy visited (two box tests each)
     uint32_t exact; // evaluations of the reference's discriminant (Source/main.cpp:475-479)
     uint32_t roots; // of those, evaluations that went on to the square root and the division (:490-499)
+    // Per section of the kernel (kSec*): how often a wave executed it, and with how many lanes enabled.
+    uint32_t sec_waves[12], sec_lanes[12];
 };
+
+enum { kSecPass = 0, kSecRefill, kSecWalkBegin, kSecNode, kSecLeafGroup, kSecRoot, kSecPointFirst, kSecPointHelp,
+       kSecScatter, kSecReplayLevel, kSecWalkSetup, kSecShade, kSecCount };
+
+// Tallies one execution of section `i` by the lanes that are enabled here.
+#define RT_TALLY(wc, i)                                                                             \
+    do {                                                                                            \
+        if (wc) {                                                                                   \
+            const unsigned long long ex_ = __builtin_amdgcn_read_exec();                            \
+            ++(wc)->sec_lanes[i];                                                                   \
+            if (__builtin_amdgcn_mbcnt_hi((uint32_t)(ex_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex_, 0u)) == 0u) \
+                ++(wc)->sec_waves[i];                                                               \
+        }                                                                                           \
+    } while (0)
 
 // ---------------------------------------------------------------------------
 // Counter-based random numbers
@@ -31,6 +47,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k1, uint32_t out[4])
 {
     uint32_t c3 = 0u;
+    // The key is wave-uniform; keep the compiler from precomputing the ten round keys once per
+    // kernel (twenty scalar registers held, and spilled, across the whole loop): formed here, they
+    // are ten scalar additions beside the vector work.
+    asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         // one 32x32->64 multiply per product (v_mad_u64_u32), not separate high and low halves

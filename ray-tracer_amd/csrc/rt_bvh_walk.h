@@ -84,6 +84,7 @@ __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, f
 {
     closest = INFINITY;
     best = -1;
+    RT_TALLY(wc, kSecWalkBegin);
     for (uint32_t i = 0; i < b.n_large; ++i)
         resolve_unordered(r, b.leaf_geom[i], (int)b.leaf_index[i], tmin, closest, best, wc);
     node = b.n_nodes ? 0 : kBvhDone;
@@ -103,6 +104,8 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
         return;
     const uint32_t suspend = n_start > b.suspend_lanes ? b.suspend_lanes : 0u;
 
+    if (walking)
+        RT_TALLY(wc, kSecWalkSetup);
     const float ox = r.ox - b.center[0], oy = r.oy - b.center[1], oz = r.oz - b.center[2];
     // reach^2 = (|o| + radius)^2 <= 2 (|o|^2 + radius^2); the hardware square root (1 ulp) is
     // inside the 1.001.  Since reff^2 >= 2^-18 reach^2, the slab roundings' 40u reach is below
@@ -137,6 +140,7 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
         while (node >= 0) {
             if (wc)
                 ++wc->nodes;
+            RT_TALLY(wc, kSecNode);
             const float4 *np = (NODES_IN_LDS ? lds_nodes : b.nodes) + (size_t)node * 4u;
             const float4 l0 = np[0], h0 = np[1], l1 = np[2], h1 = np[3];
 #define RT_SLAB(lo, hi, na, nb, nc) __builtin_fmaf(lo, na, __builtin_fmaf(hi, nb, nc))
@@ -175,6 +179,7 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
             // own candidates, so the wave pays for the most candidates any lane has, not for
             // every record some lane hits
             Geom g[4];
+            RT_TALLY(wc, kSecLeafGroup);
 #pragma unroll
             for (uint32_t j = 0u; j < 4u; ++j)
                 if (i0 + j < count)
@@ -194,6 +199,7 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
             while (cand != 0u) {
                 const uint32_t j = (uint32_t)__builtin_ctz(cand);
                 cand &= cand - 1u;
+                RT_TALLY(wc, kSecRoot);
                 const float Bs = j == 0u ? Bj[0] : j == 1u ? Bj[1] : j == 2u ? Bj[2] : Bj[3];
                 const float ds = j == 0u ? dj[0] : j == 1u ? dj[1] : j == 2u ? dj[2] : dj[3];
                 leaf_root(r, Bs, ds, b.leaf_index + (first + i0 + j), tmin, closest, best);

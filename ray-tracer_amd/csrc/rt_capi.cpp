@@ -1146,6 +1146,19 @@ int rt_get_stats(rt_context *ctx, rt_stats *stats)
     return RT_OK;
 }
 
+int rt_get_work_profile(rt_context *ctx, uint64_t *out, uint32_t n)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
+    if (!out || n > 12u)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_get_work_profile takes up to 12 sections");
+    RT_DEVICE(ctx);
+    RT_HIP(ctx, hipDeviceSynchronize());
+    RT_HIP(ctx, hipMemcpy(out, ctx->d_rays + 8, (size_t)n * 2u * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 int rt_reset_stats(rt_context *ctx)
 {
     if (!ctx)
@@ -1153,7 +1166,7 @@ int rt_reset_stats(rt_context *ctx)
     std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     RT_DEVICE(ctx);
     RT_HIP(ctx, hipDeviceSynchronize());
-    RT_HIP(ctx, hipMemset(ctx->d_rays, 0, 5 * sizeof(unsigned long long)));
+    RT_HIP(ctx, hipMemset(ctx->d_rays, 0, 256));
     ctx->last_kernel_ms = ctx->last_wall_ms = 0.0;
     return RT_OK;
 }

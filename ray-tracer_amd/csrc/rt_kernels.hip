@@ -68,11 +68,12 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long m);
 // attempts).  Must be called by all 64 lanes; `coop` = 192 words of LDS owned by the wave.
 __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixel, uint32_t sample, uint32_t &call,
                                                         uint32_t k0, uint32_t k1, uint32_t *coop, int lane,
-                                                        float &x, float &y, float &z)
+                                                        float &x, float &y, float &z, WorkCount *wc = nullptr)
 {
     bool need = want;
     if (need) {
         uint32_t w[4];
+        RT_TALLY(wc, kSecPointFirst);
         philox4x32_10(pixel, sample, call++, k0, k1, w);
         x = range_m1_p1(w[0]);
         y = range_m1_p1(w[1]);
@@ -97,6 +98,7 @@ __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixe
         bool ok = false;
         if (t < n) {
             uint32_t w[4];
+            RT_TALLY(wc, kSecPointHelp);
             philox4x32_10(coop[t], coop[64u + t], coop[128u + t] + at, k0, k1, w);
             hx = range_m1_p1(w[0]);
             hy = range_m1_p1(w[1]);
@@ -140,6 +142,43 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
 // (Source/main.cpp:551-598, 613-645), iterative.
 // ---------------------------------------------------------------------------
 
+// The kernel's arguments as they lie in its argument segment (constant memory, read with scalar
+// loads), behind a pointer the compiler cannot see through.  Arguments that a pass needs once or less
+// (camera, frame shape, hierarchy frame, output pointers) are read through this where they are used
+// instead of being held in scalar registers from the kernel's start: held, they do not fit -- the
+// compiler parks them in lanes of a vector register and fetches each back with a vector-ALU
+// instruction per use, on the pipe that limits this kernel; a scalar load costs that pipe nothing.
+typedef const __attribute__((address_space(4))) TraceArgs *ConstArgs;
+
+__device__ __forceinline__ ConstArgs fresh_args()
+{
+    ConstArgs p = (ConstArgs)__builtin_amdgcn_kernarg_segment_ptr(); // TraceArgs is the kernel's only argument
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// The hierarchy's frame, read afresh from the argument segment.
+__device__ __forceinline__ BvhArgs fresh_bvh_args()
+{
+    const ConstArgs ka = fresh_args();
+    BvhArgs b;
+    b.nodes = ka->bvh.nodes;
+    b.leaf_geom = ka->bvh.leaf_geom;
+    b.leaf_index = ka->bvh.leaf_index;
+    b.n_nodes = ka->bvh.n_nodes;
+    b.n_large = ka->bvh.n_large;
+    b.levels = ka->bvh.levels;
+    b.lds_nodes = ka->bvh.lds_nodes;
+    b.suspend_lanes = ka->bvh.suspend_lanes;
+    b.center[0] = ka->bvh.center[0];
+    b.center[1] = ka->bvh.center[1];
+    b.center[2] = ka->bvh.center[2];
+    b.radius2 = ka->bvh.radius2;
+    b.rmin = ka->bvh.rmin;
+    b.rmin2w = ka->bvh.rmin2w;
+    return b;
+}
+
 // VARIANT: kPlain the reference's behaviour and nothing else; kExt with the rt_params.flags
 // extensions compiled in; kCount kPlain plus per-lane tallies of the work the scan executes
 // (RT_OPT_COUNT_WORK; slower, same results).
@@ -149,7 +188,7 @@ template <bool MULTI_TILE, int FILTER, int VARIANT>
 __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) trace_kernel(const TraceArgs a)
 {
     constexpr bool EXT = VARIANT == kExt;
-    WorkCount work = { 0u, 0u, 0u };
+    WorkCount work = {};
     WorkCount *const wc = VARIANT == kCount ? &work : nullptr;
     extern __shared__ __align__(16) unsigned char smem[];
     Geom *tile_f = reinterpret_cast<Geom *>(smem);
@@ -225,6 +264,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
         unsigned long long need = __ballot(!active);
         while (need != 0ull && !queue_empty) {
             if (w_next >= w_end) {
+                const ConstArgs kq = fresh_args(); // the call's shape is needed once per chunk: not worth registers
                 // a new chunk needs a free accumulator slot; with both in use the idle lanes
                 // wait until one of the two chunks in flight has drained
                 const int fs = s_total0 == 0u ? 0 : (s_total1 == 0u ? 1 : -1);
@@ -233,49 +273,49 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 // The queue has kQueues heads: atomics on one address complete at about 80 million
                 // a second over the whole chip, which bounded calls with many small chunks.  A
                 // wave starts on its workgroup's queue and moves to the next when one runs dry.
-                uint32_t c = a.n_chunks;
+                uint32_t c = kq->n_chunks;
                 while (q_left != 0u) {
                     uint32_t k = 0u;
                     if (lane == 0)
-                        k = atomicAdd(a.chunk_counter + q_at * kQueueStride, 1u);
+                        k = atomicAdd(kq->chunk_counter + q_at * kQueueStride, 1u);
                     k = __builtin_amdgcn_readfirstlane(k);
-                    if (k < (a.n_chunks + (kQueues - 1u) - q_at) / kQueues) {
+                    if (k < (kq->n_chunks + (kQueues - 1u) - q_at) / kQueues) {
                         c = k * kQueues + q_at;
                         break;
                     }
                     q_at = (q_at + 1u) % kQueues;
                     --q_left;
                 }
-                if (c >= a.n_chunks) {
+                if (c >= kq->n_chunks) {
                     queue_empty = true;
                     break;
                 }
                 uint32_t k = c, sub = 0u, seg = 0u;
-                const uint32_t per_tile = a.subtiles * a.segments;
+                const uint32_t per_tile = kq->subtiles * kq->segments;
                 if (per_tile > 1u) {
                     k = c / per_tile;
                     const uint32_t r = c - k * per_tile;
-                    sub = r / a.segments;
-                    seg = r - sub * a.segments;
+                    sub = r / kq->segments;
+                    seg = r - sub * kq->segments;
                 }
-                const uint32_t seg_first = seg * a.seg_samples;
-                const uint32_t seg_count = min(a.seg_samples, a.sample_count - seg_first);
-                const uint32_t t = a.tile_first + k * a.tile_stride;
-                const uint32_t ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+                const uint32_t seg_first = seg * kq->seg_samples;
+                const uint32_t seg_count = min(kq->seg_samples, kq->sample_count - seg_first);
+                const uint32_t t = kq->tile_first + k * kq->tile_stride;
+                const uint32_t ty = t / kq->tiles_x, tx = t - ty * kq->tiles_x;
                 // the tile, clipped to the region, then the chunk's strip of it (possibly empty)
-                const int x0 = a.x0 + (int)tx * kTileW;
-                int y0 = a.y0 + (int)ty * kTileH;
-                const int tw = min(kTileW, a.x0 + a.w - x0);
-                int th = min(kTileH, a.y0 + a.h - y0);
-                if (a.subtiles > 1u) { // strips of whole tile rows: the same memory lines as the tile's
-                    const int rows = kTileH / (int)a.subtiles;
+                const int x0 = kq->x0 + (int)tx * kTileW;
+                int y0 = kq->y0 + (int)ty * kTileH;
+                const int tw = min(kTileW, kq->x0 + kq->w - x0);
+                int th = min(kTileH, kq->y0 + kq->h - y0);
+                if (kq->subtiles > 1u) { // strips of whole tile rows: the same memory lines as the tile's
+                    const int rows = kTileH / (int)kq->subtiles;
                     y0 += (int)sub * rows;
                     th = min(rows, th - (int)sub * rows);
                 }
                 const int npx = (tw > 0 && th > 0) ? tw * th : 0;
                 cur = fs;
                 s_x0[fs] = x0; s_y0[fs] = y0; s_tw[fs] = max(tw, 1); s_npx[fs] = npx;
-                s_smp[fs] = a.sample_begin + seg_first;
+                s_smp[fs] = kq->sample_begin + seg_first;
                 w_next = 0u;
                 w_smp = 0u;
                 w_pix = 0u;
@@ -289,6 +329,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             const uint32_t rank = lane_rank(need);
             const bool got = ((need >> lane) & 1ull) && rank < avail;
             if (got) {
+                RT_TALLY(wc, kSecRefill);
                 // Item w_next + rank is j = w_pix + rank pixels on from sample w_smp's first.  j / pixels
                 // and p / width as truncated float products: j < 128, pixels <= 64, so (j + 0.5) /
                 // pixels is at least 1/128 away from an integer, far more than the error of the
@@ -305,7 +346,16 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 call = 0u;
                 uint32_t w[4];
                 philox4x32_10(pixel, sample, call++, a.key0, a.key1, w);
-                camera_ray(a.cam, a.width, a.height, a.inv_width, a.inv_height, px, py, (double)unit_float(w[0]),
+                const ConstArgs ka = fresh_args();
+                rt_camera cam;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    cam.origin[q] = ka->cam.origin[q];
+                    cam.bottom_left[q] = ka->cam.bottom_left[q];
+                    cam.horizontal[q] = ka->cam.horizontal[q];
+                    cam.vertical[q] = ka->cam.vertical[q];
+                }
+                camera_ray(cam, ka->width, ka->height, ka->inv_width, ka->inv_height, px, py, (double)unit_float(w[0]),
                            (double)unit_float(w[1]), ray);
                 depth = a.max_depth; // >= 1: the host does not launch for RAY_DEPTH <= 0
                 level = 0;
@@ -334,6 +384,8 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             break;
         }
 
+        if (active)
+            RT_TALLY(wc, kSecPass);
         // ---- IntersectSceneSpheres(ray, 0.001f, inf), Source/main.cpp:562
         float closest = INFINITY;
         int best = -1;
@@ -343,10 +395,11 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             matrix_operands(ray, mine, a.shift[0], a.shift[1], a.shift[2], stage + wave * (9 * 64), lane, mo);
         bool shade = active; // the ray's closest hit is known after this pass
         if (FILTER == kFilterBvh) {
+            const BvhArgs bvh = fresh_bvh_args();
             if (active && !w_pending) { // a ray that starts its scan in this pass
                 w_pending = true;
                 if (ray.tame) {
-                    bvh_begin(a.bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best, wc);
+                    bvh_begin(bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best, wc);
                 } else { // the reference's in-order loop over the whole list, from memory
                     w_closest = INFINITY;
                     w_best = -1;
@@ -357,10 +410,10 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             if (wave_active) {
                 uint32_t *stk = reinterpret_cast<uint32_t *>(stage) + tid;
                 const bool walking = active && w_node != kBvhDone;
-                if (a.bvh.lds_nodes)
-                    bvh_walk<true>(a.bvh, bvh_lds, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best, wc);
+                if (bvh.lds_nodes)
+                    bvh_walk<true>(bvh, bvh_lds, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best, wc);
                 else
-                    bvh_walk<false>(a.bvh, nullptr, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best, wc);
+                    bvh_walk<false>(bvh, nullptr, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best, wc);
             }
             if (active && w_node == kBvhDone) {
                 w_pending = false;
@@ -406,12 +459,13 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
         const bool wants_point = material == RT_MAT_DIFFUSE || material == RT_MAT_METAL;
         float rx = 0.0f, ry = 0.0f, rz = 0.0f;
         if (__any(wants_point))
-            unit_sphere_points_wave(wants_point, pixel, sample, call, a.key0, a.key1, coop, lane, rx, ry, rz);
+            unit_sphere_points_wave(wants_point, pixel, sample, call, a.key0, a.key1, coop, lane, rx, ry, rz, wc);
 
         // ---- GetRayColor's branches, Source/main.cpp:562-597
         bool terminated = false;
         if (shade) {
             ++n_rays;
+            RT_TALLY(wc, kSecShade);
             int cr = 0, cg = 0, cb = 0;
             const bool float_shading = EXT && (a.flags & RT_FLAG_FLOAT_SHADING) != 0u;
             float fr = 0.0f, fg = 0.0f, fb = 0.0f; // terminal colour of the float-shading extension
@@ -470,6 +524,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 } else if (material == RT_MAT_DIFFUSE || material == RT_MAT_METAL) {
                     float px, py, pz, nx, ny, nz;
                     bool inside;
+                    RT_TALLY(wc, kSecScatter);
                     hit_frame(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius,
                               px, py, pz, nx, ny, nz, inside);
                     float ndx, ndy, ndz;
@@ -520,6 +575,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 // unwind the recursion: per level, bytes -> float -> bytes (:569-578, :587-591)
                 for (int l = level - 1; l >= 0; --l) {
                     const rt_sphere *sp = a.spheres + read_bounce(stack, a.stack_entry_bytes, l * kTraceThreads + tid);
+                    RT_TALLY(wc, kSecReplayLevel);
                     if (sp->material == RT_MAT_DIFFUSE) {
                         cr >>= 1; cg >>= 1; cb >>= 1;
                     }
@@ -546,8 +602,9 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 const uint32_t total = sl ? s_total1 : s_total0, done = sl ? s_done1 : s_done0;
                 if (total != 0u && done == total) {
                     if (lane < s_npx[sl]) {
+                        const ConstArgs ka = fresh_args();
                         const int ly = lane / s_tw[sl], lx = lane - ly * s_tw[sl];
-                        uint32_t *dst = a.sums + ((size_t)(s_x0[sl] + lx) + (size_t)(s_y0[sl] + ly) * a.width) * 3u;
+                        uint32_t *dst = ka->sums + ((size_t)(s_x0[sl] + lx) + (size_t)(s_y0[sl] + ly) * ka->width) * 3u;
                         uint32_t *src = acc + sl * 192 + lane * 3;
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch) {
@@ -585,6 +642,18 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             atomicAdd(a.rays + 2, w0);
             atomicAdd(a.rays + 3, w1);
             atomicAdd(a.rays + 4, w2);
+        }
+        for (int i = 0; i < kSecCount; ++i) { // [8 + 2i] wave executions, [9 + 2i] lane executions of section i
+            unsigned long long sw = work.sec_waves[i], sl = work.sec_lanes[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                sw += __shfl_down(sw, off, 64);
+                sl += __shfl_down(sl, off, 64);
+            }
+            if (lane == 0) {
+                atomicAdd(a.rays + 8 + 2 * i, sw);
+                atomicAdd(a.rays + 9 + 2 * i, sl);
+            }
         }
     }
 }

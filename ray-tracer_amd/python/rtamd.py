@@ -32,7 +32,7 @@ EXPORTS = [
     "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_device_count", "rt_multi_uses_rccl",
     "rt_multi_context", "rt_multi_set_scene", "rt_multi_set_option", "rt_multi_render", "rt_multi_render_device",
     "rt_multi_synchronize", "rt_multi_get_stats", "rt_multi_reset_stats",
-    "rt_tile_block_bytes", "rt_pack_tiles_device", "rt_unpack_tiles_device", "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_accel_selfcheck", "rt_get_stats", "rt_reset_stats",
+    "rt_tile_block_bytes", "rt_pack_tiles_device", "rt_unpack_tiles_device", "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_accel_selfcheck", "rt_get_stats", "rt_reset_stats", "rt_get_work_profile",
 ]
 
 
@@ -141,6 +141,8 @@ def load():
     L.rt_set_option.argtypes = [vp, i, C.c_int64]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_reset_stats.argtypes = [vp]
+    if hasattr(L, "rt_get_work_profile"):  # absent from older builds kept for A/B timing (RTAMD_LIBRARY)
+        L.rt_get_work_profile.argtypes = [vp, C.POINTER(C.c_uint64), u32]
     _lib = L
     return L
 
@@ -291,6 +293,15 @@ class Context:
 
     def reset_stats(self):
         self._check(self._L.rt_reset_stats(self._h))
+
+    SECTIONS = ["pass", "refill", "walk_begin", "node", "leaf_group", "root", "point_first", "point_help", "scatter",
+                "replay_level", "walk_setup", "shade"]
+
+    def work_profile(self):
+        """{section: (wave executions, lane executions)} of the counting build since the last reset."""
+        out = (C.c_uint64 * 24)()
+        self._check(self._L.rt_get_work_profile(self._h, out, 12))
+        return {name: (int(out[2 * i]), int(out[2 * i + 1])) for i, name in enumerate(self.SECTIONS)}
 
 
 def tile_block_bytes(width, height, tile_first, tile_stride):
