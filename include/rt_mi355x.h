@@ -283,7 +283,7 @@ typedef enum rt_option {
     RT_OPT_FILTER = 0,
     RT_OPT_TILE_SPHERES = 1,      /* spheres per LDS tile, 128..4096 (default 512) */
     RT_OPT_WORKGROUPS_PER_CU = 2, /* cap on resident workgroups per CU, 0 = occupancy limit */
-    RT_OPT_BVH_LEAF_SPHERES = 3,  /* most spheres per leaf of the hierarchy, 1..15 (default 4) */
+    RT_OPT_BVH_LEAF_SPHERES = 3,  /* most spheres per leaf of the hierarchy, 1..15 (default: 4, or 8 for trees too large for LDS) */
     RT_OPT_BVH_MIN_SPHERES = 4,   /* scene size from which the automatic choice is the hierarchy */
     RT_OPT_BVH_LDS_NODES = 5,     /* hierarchies of up to this many nodes are walked in LDS, 0..2048 (default 512) */
     RT_OPT_BVH_SUSPEND_LANES = 6, /* a 64-lane wave stops walking the hierarchy when at most this many of its rays
@@ -314,7 +314,10 @@ int rt_reset_stats(rt_context *ctx);
  * trace kernel -- 0 wave pass, 1 refill, 2 walk start (always-tested spheres), 3 hierarchy node, 4 group of
  * up to four leaf records, 5 root evaluation, 6 first random-point attempt, 7 helper attempt, 8 scatter,
  * 9 replay of one recursion level, 10 walk set-up, 11 shading -- out[2i] = how many times a 64-lane wave
- * executed the section and out[2i+1] = with how many lanes enabled in total, since the last reset. */
+ * executed the section and out[2i+1] = with how many lanes enabled in total, since the last reset.
+ * Pairs 12..16 hold shader-clock cycles instead, summed over the waves: out[24] wave lifetime, [25] waiting
+ * for the work queue, [26] refill (queue included), [27] sphere scan, [28] random points, [29] shading and
+ * replay, [30] flush of chunk sums, [32] the number of waves (n <= 28 pairs). */
 int rt_get_work_profile(rt_context *ctx, uint64_t *out, uint32_t n);
 
 #ifdef __cplusplus

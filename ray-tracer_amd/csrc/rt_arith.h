@@ -22,7 +22,21 @@ struct WorkCount {
     uint32_t roots; // of those, evaluations that went on to the square root and the division (:490-499)
     // Per section of the kernel (kSec*): how often a wave executed it, and with how many lanes enabled.
     uint32_t sec_waves[12], sec_lanes[12];
+    // Shader-clock cycles a wave spent in a phase of its passes (kTime*), summed over its lifetime.
+    unsigned long long time[8];
 };
+
+enum { kTimeLife = 0, kTimeFetch, kTimeRefill, kTimeScan, kTimePoints, kTimeShade, kTimeFlush, kTimeCount };
+
+// Adds the cycles since `since` to phase `i` and restarts the clock (counting build only).
+#define RT_CLOCK(wc, i, since)                                         \
+    do {                                                               \
+        if (wc) {                                                      \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+            (wc)->time[i] += now_ - (since);                           \
+            (since) = now_;                                            \
+        }                                                              \
+    } while (0)
 
 enum { kSecPass = 0, kSecRefill, kSecWalkBegin, kSecNode, kSecLeafGroup, kSecRoot, kSecPointFirst, kSecPointHelp,
        kSecScatter, kSecReplayLevel, kSecWalkSetup, kSecShade, kSecCount };

@@ -190,6 +190,8 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
     constexpr bool EXT = VARIANT == kExt;
     WorkCount work = {};
     WorkCount *const wc = VARIANT == kCount ? &work : nullptr;
+    const unsigned long long t_start = VARIANT == kCount ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_mark = t_start;
     extern __shared__ __align__(16) unsigned char smem[];
     Geom *tile_f = reinterpret_cast<Geom *>(smem);
     Geom *tile_e = tile_f + a.tile_cap;
@@ -274,6 +276,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 // a second over the whole chip, which bounded calls with many small chunks.  A
                 // wave starts on its workgroup's queue and moves to the next when one runs dry.
                 uint32_t c = kq->n_chunks;
+                unsigned long long t_fetch = wc ? __builtin_amdgcn_s_memtime() : 0ull;
                 while (q_left != 0u) {
                     uint32_t k = 0u;
                     if (lane == 0)
@@ -286,6 +289,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                     q_at = (q_at + 1u) % kQueues;
                     --q_left;
                 }
+                RT_CLOCK(wc, kTimeFetch, t_fetch);
                 if (c >= kq->n_chunks) {
                     queue_empty = true;
                     break;
@@ -371,6 +375,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             need &= ~__ballot(got);
         }
 
+        RT_CLOCK(wc, kTimeRefill, t_mark);
         // ---- termination
         const bool wave_active = __any(active);
         if (MULTI_TILE) {
@@ -450,6 +455,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
         }
         if (wave_active)
             ++n_rounds;
+        RT_CLOCK(wc, kTimeScan, t_mark);
 
         // ---- the random point of the Diffuse and Metal branches (:566, :584), drawn for the
         // whole wave at once; nothing else draws between the hit and this point
@@ -461,6 +467,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
         if (__any(wants_point))
             unit_sphere_points_wave(wants_point, pixel, sample, call, a.key0, a.key1, coop, lane, rx, ry, rz, wc);
 
+        RT_CLOCK(wc, kTimePoints, t_mark);
         // ---- GetRayColor's branches, Source/main.cpp:562-597
         bool terminated = false;
         if (shade) {
@@ -591,6 +598,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             }
         }
 
+        RT_CLOCK(wc, kTimeShade, t_mark);
         // ---- chunks whose last path has just terminated: add their sums to the frame
         const unsigned long long term = __ballot(terminated);
         if (term != 0ull) {
@@ -619,6 +627,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 }
             }
         }
+        RT_CLOCK(wc, kTimeFlush, t_mark);
     }
 
     // ---- ray counter: one atomic per wave
@@ -654,6 +663,12 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 atomicAdd(a.rays + 8 + 2 * i, sw);
                 atomicAdd(a.rays + 9 + 2 * i, sl);
             }
+        }
+        work.time[kTimeLife] = __builtin_amdgcn_s_memtime() - t_start;
+        if (lane == 0) { // [32 + i] cycles in phase i, [40] waves
+            for (int i = 0; i < kTimeCount; ++i)
+                atomicAdd(a.rays + 32 + i, work.time[i]);
+            atomicAdd(a.rays + 40, 1ull);
         }
     }
 }

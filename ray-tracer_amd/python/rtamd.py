@@ -299,9 +299,12 @@ class Context:
 
     def work_profile(self):
         """{section: (wave executions, lane executions)} of the counting build since the last reset."""
-        out = (C.c_uint64 * 24)()
-        self._check(self._L.rt_get_work_profile(self._h, out, 12))
-        return {name: (int(out[2 * i]), int(out[2 * i + 1])) for i, name in enumerate(self.SECTIONS)}
+        out = (C.c_uint64 * 56)()
+        self._check(self._L.rt_get_work_profile(self._h, out, 28))
+        prof = {name: (int(out[2 * i]), int(out[2 * i + 1])) for i, name in enumerate(self.SECTIONS)}
+        prof["cycles"] = dict(zip(["life", "fetch", "refill", "scan", "points", "shade", "flush"], [int(v) for v in out[24:31]]))
+        prof["cycles"]["waves"] = int(out[32])
+        return prof
 
 
 def tile_block_bytes(width, height, tile_first, tile_stride):
