@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the list-scan leg and the counting launches (N = 1 only has them)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N > 1: nccl = RCCL, one GPU per rank (the measured configuration); gloo = rehearsal of the N > 1 "
+                         "path on fewer GPUs than ranks (ranks share devices, exchanged buffers go through the host)")
     ap.add_argument("--scan", choices=sorted(SCANS), default="auto",
                     help="how rays find their candidate spheres (all give the same frame); auto = the library's choice")
     args = ap.parse_args()
@@ -153,16 +156,21 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    rehearsal = world > 1 and args.backend == "gloo"
+    device_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     global W, H, SPP, N_SPHERES
     W, H, SPP, N_SPHERES, grid, default_partition = WORKLOADS[args.workload]
     if args.partition is None:
         args.partition = default_partition if args.scaling == "strong" else "samples"
-    ctx = rtamd.Context(local_rank)
+    ctx = rtamd.Context(device_index)
     scene = scenes.random_spheres(N_SPHERES, grid_half=grid)
     ctx.set_scene(scene)
     ctx.set_option(rtamd.OPT_FILTER, SCANS[args.scan])
@@ -194,7 +202,8 @@ def main():
         unpack_tiles = staticmethod(tracer.unpack_tiles)
 
     timed = TimedTracer()
-    pipe = dist_render.FramePipeline(timed, p, (W, H, total_spp), args.partition, rank, world, dist, torch, "cuda")
+    pipe = dist_render.FramePipeline(timed, p, (W, H, total_spp), args.partition, rank, world, dist, torch, "cuda",
+                                     host_exchange=rehearsal)
 
     def fence():
         torch.cuda.synchronize()
@@ -249,7 +258,8 @@ def main():
 
     if world > 1:
         dist.barrier()
-    t = torch.tensor([elapsed, float(st.rays), float(st.wave_passes), kernel_ms], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed, float(st.rays), float(st.wave_passes), kernel_ms], dtype=torch.float64,
+                     device="cpu" if rehearsal else "cuda")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -281,7 +291,7 @@ def main():
             "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL over gloo: ranks share GPUs, not a measurement)",
             "config": {
                 "workload": WORKLOAD_TEXT[args.workload] + (" per GPU (weak scaling)" if world > 1 and args.scaling == "weak" else ""),
                 "spheres": N_SPHERES, "width": W, "height": H, "frame_spp": total_spp,

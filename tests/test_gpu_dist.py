@@ -73,3 +73,28 @@ def test_two_processes_on_the_device_assemble_the_oracle_frame(tmp_path, partiti
     assert np.array_equal(got, want)
     piped = np.load(out + ".pipe.npy")
     assert np.array_equal(piped[0], want) and np.array_equal(piped[1], want)
+
+
+@pytest.mark.parametrize("extra,rays", [(["--partition", "tiles"], 301321686), (["--partition", "samples"], 301321686),
+                                        (["--scaling", "weak"], None)])
+def test_bench_multi_rank_path_rehearsed_on_one_gpu(extra, rays):
+    """bench.py's N > 1 path (rank shares, pipelined exchange, max-over-ranks timing, the JSON line) with
+    two ranks sharing the GPU over gloo: not a measurement, but every line of that path runs.  The
+    strong-scaling frame must trace exactly the single-GPU frame's rays."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", *extra]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=280, cwd=root).stdout
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["unit"] == "Mrays/s"
+    assert "REHEARSAL" in line["data"]
+    if rays is not None:
+        assert line["scaling"] == "strong" and line["rays_per_step"] == rays and line["config"]["frame_spp"] == 64
+    else:
+        assert line["scaling"] == "weak" and line["config"]["frame_spp"] == 128 and line["rays_per_step"] > 2 * 301000000
+    assert line["value"] > 0 and line["ms_per_step"] > 0
