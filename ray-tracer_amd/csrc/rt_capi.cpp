@@ -20,6 +20,8 @@
 
 using namespace rtamd;
 
+constexpr size_t kCounterBytes = (size_t)kCounterSlots * kCounterWords * sizeof(unsigned long long);
+
 // Geometry lists and LDS tiles are padded to whole candidate groups of the matrix scan.
 static constexpr uint32_t kPad = 128;
 
@@ -142,6 +144,19 @@ private:
 struct Region {
     int x0, y0, w, h;
 };
+
+// The device's counters, summed over their kCounterSlots copies (the caller has synchronised).
+int read_counters(rt_context *ctx, unsigned long long out[kCounterWords])
+{
+    std::vector<unsigned long long> all((size_t)kCounterSlots * kCounterWords);
+    RT_HIP(ctx, hipMemcpy(all.data(), ctx->d_rays, kCounterBytes, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < kCounterWords; ++i) {
+        out[i] = 0;
+        for (uint32_t s = 0; s < kCounterSlots; ++s)
+            out[i] += all[(size_t)s * kCounterWords + i];
+    }
+    return RT_OK;
+}
 
 // Preconditions of the conservative filters' error bounds and of the hierarchy builder: every
 // magnitude finite and below 2^28, r*r at least 2^-40.  Written as comparisons that are false
@@ -430,6 +445,9 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     const uint32_t by_chunks = (a.n_chunks + 3u) / 4u;
     if (n_wg > by_chunks)
         n_wg = by_chunks;
+    a.n_queues = 1u;
+    while (a.n_queues * 2u <= kQueues && a.n_queues * 2u <= n_wg)
+        a.n_queues *= 2u;
 
     if (ctx->trace_enqueued)
         RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_trace, 0));
@@ -488,9 +506,9 @@ int rt_create(int device_id, rt_context **out)
         hipEventCreateWithFlags(&ctx->ev_trace, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->ev_t0) != hipSuccess || hipEventCreate(&ctx->ev_t1) != hipSuccess ||
         hipMalloc((void **)&ctx->d_chunk_counter, kQueues * kQueueStride * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_rays, 512) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_rays, kCounterBytes) != hipSuccess ||
         static_scratch_address(&ctx->static_scratch) != hipSuccess || ctx->static_scratch == nullptr ||
-        hipMemset(ctx->d_rays, 0, 512) != hipSuccess) {
+        hipMemset(ctx->d_rays, 0, kCounterBytes) != hipSuccess) {
         rt_destroy(ctx);
         return RT_ERR_HIP;
     }
@@ -1143,8 +1161,10 @@ int rt_get_stats(rt_context *ctx, rt_stats *stats)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null stats");
     RT_DEVICE(ctx);
     RT_HIP(ctx, hipDeviceSynchronize());
-    unsigned long long counters[5] = { 0, 0, 0, 0, 0 };
-    RT_HIP(ctx, hipMemcpy(counters, ctx->d_rays, sizeof counters, hipMemcpyDeviceToHost));
+    unsigned long long counters[kCounterWords];
+    const int cst = read_counters(ctx, counters);
+    if (cst != RT_OK)
+        return cst;
     stats->node_visits = counters[2];
     stats->exact_tests = counters[3];
     stats->root_evaluations = counters[4];
@@ -1165,7 +1185,12 @@ int rt_get_work_profile(rt_context *ctx, uint64_t *out, uint32_t n)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_get_work_profile takes up to 28 pairs");
     RT_DEVICE(ctx);
     RT_HIP(ctx, hipDeviceSynchronize());
-    RT_HIP(ctx, hipMemcpy(out, ctx->d_rays + 8, (size_t)n * 2u * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    unsigned long long counters[kCounterWords];
+    const int cst = read_counters(ctx, counters);
+    if (cst != RT_OK)
+        return cst;
+    for (uint32_t i = 0; i < 2u * n; ++i)
+        out[i] = counters[8u + i];
     return RT_OK;
 }
 
@@ -1176,7 +1201,7 @@ int rt_reset_stats(rt_context *ctx)
     std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
     RT_DEVICE(ctx);
     RT_HIP(ctx, hipDeviceSynchronize());
-    RT_HIP(ctx, hipMemset(ctx->d_rays, 0, 512));
+    RT_HIP(ctx, hipMemset(ctx->d_rays, 0, kCounterBytes));
     ctx->last_kernel_ms = ctx->last_wall_ms = 0.0;
     return RT_OK;
 }

@@ -11,8 +11,18 @@ namespace rtamd {
 
 // Threads per workgroup of the trace kernel: 4 waves, one per SIMD of a CU.
 constexpr int kTraceThreads = 256;
-constexpr uint32_t kQueues = 8;       // heads of the chunk queue (one address completes ~80 M atomics/s)
-constexpr uint32_t kQueueStride = 64; // words between heads: separate 256-byte blocks
+// Atomics on one address complete at only 40 to 80 million a second over the whole chip, and a launch
+// has thousands of waves.  So the chunk queue has kQueues heads in separate 256-byte blocks (head q
+// hands out chunks q, q + n_queues, ...; a launch uses n_queues of them, a power of two not above its
+// number of workgroups, so that every head has workgroups of its own), a wave that finds its head
+// dry tries only the next kQueueProbes - 1 heads before it retires (every head is drained by its own
+// waves; chunks are dealt to heads round robin, so the heads carry equal samples of the frame), and
+// the counters the waves add to at their end are kCounterSlots copies, summed on the host.
+constexpr uint32_t kQueues = 64;
+constexpr uint32_t kQueueStride = 64; // words between heads
+constexpr uint32_t kQueueProbes = 4;
+constexpr uint32_t kCounterSlots = 64;
+constexpr uint32_t kCounterWords = 64; // 64-bit counters per slot
 // Pixel tile one wave draws its samples from (also rt_params' tile unit).
 constexpr int kTileW = 8;
 constexpr int kTileH = 8;
@@ -74,9 +84,11 @@ struct TraceArgs {
     // (c / segments) % subtiles, segment c % segments.  A strip clipped away by the region's
     // edge is an empty chunk.  With segments > 1 several waves add into the same pixels of `sums`.
     uint32_t n_chunks, subtiles, segments, seg_samples;
+    uint32_t n_queues;         // heads of the work queue in use: a power of two <= min(kQueues, workgroups)
     uint32_t *sums;            // full frame uint32 x3
-    unsigned long long *rays;  // [0] ray counter, [1] wave passes over the sphere list; counting build:
-                               // [2] hierarchy nodes visited, [3] exact discriminants, [4] root evaluations
+    unsigned long long *rays;  // kCounterSlots x kCounterWords counters; a workgroup adds to slot blockIdx % kCounterSlots:
+                               // [0] rays, [1] wave passes over the sphere list; counting build: [2] hierarchy
+                               // nodes visited, [3] exact discriminants, [4] root evaluations, [8..] section tallies
     // Work queue heads, zeroed before launch: kQueues counters kQueueStride words apart; queue q
     // hands out chunks q, q + kQueues, q + 2 kQueues, ...
     uint32_t *chunk_counter;

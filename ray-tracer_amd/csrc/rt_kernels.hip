@@ -237,7 +237,9 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
 
     // wave-uniform queue state; slot s is free while s_total[s] == 0
     uint32_t w_next = 0u, w_end = 0u;
-    uint32_t q_at = blockIdx.x % kQueues, q_left = kQueues; // queue in use, queues not yet found empty
+    // queue in use (every queue has workgroups of its own, which stay until it is empty), and how many
+    // queues the wave may still try before it retires
+    uint32_t q_at = blockIdx.x & (a.n_queues - 1u), q_left = min(kQueueProbes, a.n_queues);
     // item w_next of the current chunk is pixel w_pix of sample w_smp: w_next = w_smp * pixels + w_pix
     uint32_t w_smp = 0u, w_pix = 0u;
     float w_inv_npx = 1.0f, w_inv_tw = 1.0f; // reciprocals of the chunk's pixel count and width
@@ -282,11 +284,11 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                     if (lane == 0)
                         k = atomicAdd(kq->chunk_counter + q_at * kQueueStride, 1u);
                     k = __builtin_amdgcn_readfirstlane(k);
-                    if (k < (kq->n_chunks + (kQueues - 1u) - q_at) / kQueues) {
-                        c = k * kQueues + q_at;
+                    if (k < (kq->n_chunks + (kq->n_queues - 1u) - q_at) / kq->n_queues) {
+                        c = k * kq->n_queues + q_at;
                         break;
                     }
-                    q_at = (q_at + 1u) % kQueues;
+                    q_at = (q_at + 1u) & (kq->n_queues - 1u);
                     --q_left;
                 }
                 RT_CLOCK(wc, kTimeFetch, t_fetch);
@@ -635,9 +637,10 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
         total += __shfl_down(total, off, 64);
+    unsigned long long *counters = a.rays + (size_t)(blockIdx.x % kCounterSlots) * kCounterWords;
     if (lane == 0 && total != 0ull) {
-        atomicAdd(a.rays, total);
-        atomicAdd(a.rays + 1, (unsigned long long)n_rounds);
+        atomicAdd(counters, total);
+        atomicAdd(counters + 1, (unsigned long long)n_rounds);
     }
     if (VARIANT == kCount) { // executed work: [2] node visits, [3] discriminants, [4] root evaluations
         unsigned long long w0 = work.nodes, w1 = work.exact, w2 = work.roots;
@@ -648,9 +651,9 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             w2 += __shfl_down(w2, off, 64);
         }
         if (lane == 0) {
-            atomicAdd(a.rays + 2, w0);
-            atomicAdd(a.rays + 3, w1);
-            atomicAdd(a.rays + 4, w2);
+            atomicAdd(counters + 2, w0);
+            atomicAdd(counters + 3, w1);
+            atomicAdd(counters + 4, w2);
         }
         for (int i = 0; i < kSecCount; ++i) { // [8 + 2i] wave executions, [9 + 2i] lane executions of section i
             unsigned long long sw = work.sec_waves[i], sl = work.sec_lanes[i];
@@ -660,15 +663,15 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 sl += __shfl_down(sl, off, 64);
             }
             if (lane == 0) {
-                atomicAdd(a.rays + 8 + 2 * i, sw);
-                atomicAdd(a.rays + 9 + 2 * i, sl);
+                atomicAdd(counters + 8 + 2 * i, sw);
+                atomicAdd(counters + 9 + 2 * i, sl);
             }
         }
         work.time[kTimeLife] = __builtin_amdgcn_s_memtime() - t_start;
         if (lane == 0) { // [32 + i] cycles in phase i, [40] waves
             for (int i = 0; i < kTimeCount; ++i)
-                atomicAdd(a.rays + 32 + i, work.time[i]);
-            atomicAdd(a.rays + 40, 1ull);
+                atomicAdd(counters + 32 + i, work.time[i]);
+            atomicAdd(counters + 40, 1ull);
         }
     }
 }
