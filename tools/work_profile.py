@@ -23,6 +23,7 @@ ctx.accumulate_device(cam, rtamd.params(1920, 1080, 64, 8, seed=1), d.data_ptr()
 torch.cuda.synchronize()
 st = ctx.stats()
 prof = ctx.work_profile()
+prof.pop("cycles", None)
 passes = prof["pass"][0]
 print(f"rays {st.rays}  wave passes {passes}  rays per pass {st.rays / passes:.1f}")
 print(f"{'section':14s} {'per pass':>9s} {'lanes on':>9s} {'lane-executions per ray':>24s}")
