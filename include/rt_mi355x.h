@@ -293,6 +293,9 @@ typedef enum rt_option {
                                      into segments, chunks of at least 256 paths; segments add into the frame with
                                      atomics (0..256, default 16, 0 = never cut).  Results do not depend on it. */
     RT_OPT_SUBTILES = 8,          /* most strips of rows a tile is cut into before its samples are: 1, 2 or 4 (default) */
+    RT_OPT_DIRECT_ADD_SAMPLES = 10, /* calls (or cut chunks) of at most this many samples per pixel add every path's colour to the
+                                     frame with atomics of its own instead of through per-chunk sums in LDS, so that a wave
+                                     never waits for a chunk to drain (0..64, default 1, 0 = never).  Results do not depend on it. */
     RT_OPT_COUNT_WORK = 9         /* 1: trace with the counting build, which fills rt_stats' node_visits, exact_tests and
                                      root_evaluations (slower; for measurement); 0 (default): those stay 0 */
 } rt_option;

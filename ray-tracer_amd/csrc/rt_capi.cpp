@@ -51,6 +51,7 @@ struct rt_context {
     uint32_t bvh_lds_nodes_max = 512; // trees up to this many nodes (64 B each) are walked in LDS
     uint32_t subtiles_max = 4;     // work queue: tiles may be cut into this many strips of rows (1, 2 or 4)
     uint32_t chunks_per_wave = 16; // work queue: split tiles' samples until there are this many chunks per resident wave
+    uint32_t direct_add_samples = 1; // RT_OPT_DIRECT_ADD_SAMPLES
     bool count_work = false;       // RT_OPT_COUNT_WORK: launch the counting build of the trace kernel
     uint32_t bvh_auto_min = 64;    // automatic choice: hierarchy from this many spheres up (measured crossover)
     float4 *d_bvh_nodes = nullptr;
@@ -442,6 +443,7 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
             a.n_chunks = (uint32_t)total;
         }
     }
+    a.direct_add = a.seg_samples <= ctx->direct_add_samples ? 1u : 0u;
     const uint32_t by_chunks = (a.n_chunks + 3u) / 4u;
     if (n_wg > by_chunks)
         n_wg = by_chunks;
@@ -1102,6 +1104,11 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
         if (value != 1 && value != 2 && value != 4)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_SUBTILES takes 1, 2 or 4");
         ctx->subtiles_max = (uint32_t)value;
+        return RT_OK;
+    case RT_OPT_DIRECT_ADD_SAMPLES:
+        if (value < 0 || value > 64)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_DIRECT_ADD_SAMPLES takes 0..64");
+        ctx->direct_add_samples = (uint32_t)value;
         return RT_OK;
     case RT_OPT_COUNT_WORK:
         if (value != 0 && value != 1)

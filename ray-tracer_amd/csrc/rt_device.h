@@ -85,6 +85,10 @@ struct TraceArgs {
     // edge is an empty chunk.  With segments > 1 several waves add into the same pixels of `sums`.
     uint32_t n_chunks, subtiles, segments, seg_samples;
     uint32_t n_queues;         // heads of the work queue in use: a power of two <= min(kQueues, workgroups)
+    // Chunks of very few samples: every path adds its colour to `sums` itself (three atomics) instead of
+    // through the wave's two per-chunk accumulators, so a wave never waits for a chunk to drain
+    // before it may pull the next one.
+    uint32_t direct_add;
     uint32_t *sums;            // full frame uint32 x3
     unsigned long long *rays;  // kCounterSlots x kCounterWords counters; a workgroup adds to slot blockIdx % kCounterSlots:
                                // [0] rays, [1] wave passes over the sphere list; counting build: [2] hierarchy

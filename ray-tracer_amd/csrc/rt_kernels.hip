@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 const ConstArgs kq = fresh_args(); // the call's shape is needed once per chunk: not worth registers
                 // a new chunk needs a free accumulator slot; with both in use the idle lanes
                 // wait until one of the two chunks in flight has drained
-                const int fs = s_total0 == 0u ? 0 : (s_total1 == 0u ? 1 : -1);
+                const int fs = kq->direct_add ? 0 : (s_total0 == 0u ? 0 : (s_total1 == 0u ? 1 : -1));
                 if (fs < 0)
                     break;
                 // The queue has kQueues heads: atomics on one address complete at about 80 million
@@ -328,7 +328,8 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 w_inv_npx = __builtin_amdgcn_rcpf((float)max(npx, 1));
                 w_inv_tw = __builtin_amdgcn_rcpf((float)max(tw, 1));
                 w_end = (uint32_t)npx * seg_count;
-                if (fs == 0) { s_total0 = w_end; s_done0 = 0u; } else { s_total1 = w_end; s_done1 = 0u; }
+                if (kq->direct_add) { // no accumulator to flush: the slot stays free
+                } else if (fs == 0) { s_total0 = w_end; s_done0 = 0u; } else { s_total1 = w_end; s_done1 = 0u; }
             }
             const int ch_x0 = s_x0[cur], ch_y0 = s_y0[cur], ch_tw = s_tw[cur], ch_npx = s_npx[cur];
             const uint32_t avail = w_end - w_next;
@@ -576,9 +577,17 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                     fg = limit_255(sp->color[1] * fg);
                     fb = limit_255(sp->color[2] * fb);
                 }
-                atomicAdd(acc + acc_at + 0u, (uint32_t)to_byte(fr));
-                atomicAdd(acc + acc_at + 1u, (uint32_t)to_byte(fg));
-                atomicAdd(acc + acc_at + 2u, (uint32_t)to_byte(fb));
+                const ConstArgs kt = fresh_args();
+                if (kt->direct_add) {
+                    uint32_t *dst = kt->sums + (size_t)pixel * 3u;
+                    atomicAdd(dst + 0, (uint32_t)to_byte(fr));
+                    atomicAdd(dst + 1, (uint32_t)to_byte(fg));
+                    atomicAdd(dst + 2, (uint32_t)to_byte(fb));
+                } else {
+                    atomicAdd(acc + acc_at + 0u, (uint32_t)to_byte(fr));
+                    atomicAdd(acc + acc_at + 1u, (uint32_t)to_byte(fg));
+                    atomicAdd(acc + acc_at + 2u, (uint32_t)to_byte(fb));
+                }
                 active = false;
             } else if (terminated) {
                 // unwind the recursion: per level, bytes -> float -> bytes (:569-578, :587-591)
@@ -593,9 +602,17 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                     cb = to_byte(sp->color[2] * (float)cb);
                 }
                 // FinalColor += ray_color, :633-635
-                atomicAdd(acc + acc_at + 0u, (uint32_t)cr);
-                atomicAdd(acc + acc_at + 1u, (uint32_t)cg);
-                atomicAdd(acc + acc_at + 2u, (uint32_t)cb);
+                const ConstArgs kt = fresh_args();
+                if (kt->direct_add) {
+                    uint32_t *dst = kt->sums + (size_t)pixel * 3u;
+                    atomicAdd(dst + 0, (uint32_t)cr);
+                    atomicAdd(dst + 1, (uint32_t)cg);
+                    atomicAdd(dst + 2, (uint32_t)cb);
+                } else {
+                    atomicAdd(acc + acc_at + 0u, (uint32_t)cr);
+                    atomicAdd(acc + acc_at + 1u, (uint32_t)cg);
+                    atomicAdd(acc + acc_at + 2u, (uint32_t)cb);
+                }
                 active = false;
             }
         }

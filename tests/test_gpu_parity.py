@@ -422,6 +422,37 @@ def test_split_sample_ranges_give_the_same_sums(ctx, torch, filt):
         ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
 
 
+@pytest.mark.parametrize("filt", [rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_BVH])
+def test_direct_adds_of_low_sample_calls_give_the_same_sums(ctx, torch, filt):
+    """Calls of very few samples per pixel let every path add its colour to the frame itself
+    (RT_OPT_DIRECT_ADD_SAMPLES) instead of through the per-chunk sums: same sums, same rays, also
+    into a buffer that already holds values, for whole frames, tiles, slices and cut chunks."""
+    sc = c3_scene()
+    ctx.set_scene(sc)
+    ctx.set_option(rtamd.OPT_FILTER, filt)
+    cam = rtamd.make_camera(*C3_CAM)
+    W, H, D = 61, 43, 6
+    try:
+        for spp, kw in ((1, {}), (2, {}), (3, {}), (5, dict(sample_begin=2, sample_count=1)), (24, dict(tile_first=1, tile_stride=3))):
+            p = rtamd.params(W, H, spp, D, seed=31, **kw)
+            out = []
+            for direct in (0, 1, 64):
+                ctx.set_option(rtamd.OPT_DIRECT_ADD_SAMPLES, direct)
+                d = torch.full((H * W * 3,), 7, dtype=torch.int32, device="cuda")
+                ctx.reset_stats()
+                ctx.accumulate_device(cam, p, d.data_ptr())
+                torch.cuda.synchronize()
+                out.append((d.cpu().numpy(), ctx.stats().rays))
+            assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][0], out[2][0]), (spp, kw)
+            assert out[0][1] == out[1][1] == out[2][1]
+            if not kw:
+                _, sums_o, rays_o = O.trace_tile(sc, O.camera(*C3_CAM), W, H, spp, D, O.RNG_COUNTER, seed=31, want_sums=True)
+                assert np.array_equal(out[2][0].view(np.uint32).reshape(H, W, 3) - 7, sums_o) and out[2][1] == rays_o
+    finally:
+        ctx.set_option(rtamd.OPT_DIRECT_ADD_SAMPLES, 1)
+        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
+
+
 def test_random_calls_do_not_depend_on_how_the_queue_cuts_them(ctx, torch):
     """Random frame sizes, regions (some hanging over the frame), sample slices and interleaved tile
     sets, each traced with whole-tile chunks and with random cuts: same sums, same ray count."""

@@ -15,8 +15,8 @@ ctx.set_scene(scenes.random_spheres(500))
 cam = rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA)
 d = torch.zeros(1920 * 1080 * 3, dtype=torch.int32, device="cuda")
 for spp in (1, 2, 4, 8, 16):
-    for direct in (0,):
-        pass
+    for direct in (0, 1, 2, 4):
+        ctx.set_option(rtamd.OPT_DIRECT_ADD_SAMPLES, direct)
         p = rtamd.params(1920, 1080, spp, 8, seed=1)
         d.zero_()
         ctx.accumulate_device(cam, p, d.data_ptr())
