@@ -187,7 +187,10 @@ int rt_render_device_static(rt_context *ctx, const rt_camera *cam, const rt_para
 /* The sample loop of Source/main.cpp:623-636 for samples [sample_begin,
  * sample_begin+sample_count) and the tiles selected by tile_first/tile_stride:
  * ADDS each sample's byte colour into `d_sums` (full frame, width*height*3
- * uint32, index (x + y*width)*3 + channel).  The caller zeroes d_sums. */
+ * uint32, index (x + y*width)*3 + channel).  The caller zeroes d_sums.  Calls of ONE context on
+ * the same d_sums are ordered by the library; calls of DIFFERENT contexts (or devices) into the same
+ * d_sums must not overlap in time: a chunk's sums are added with plain loads and stores wherever the
+ * launch owns the chunk's pixels. */
 int rt_accumulate_device(rt_context *ctx, const rt_camera *cam, const rt_params *params,
                          int xstart, int ystart, int xsize, int ysize, uint32_t *d_sums,
                          void *stream);
