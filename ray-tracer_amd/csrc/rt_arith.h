@@ -14,6 +14,13 @@
 namespace rtamd {
 namespace {
 
+// The lanes for which `p` holds, as a mask: the compare that produced `p` already left exactly this
+// in a scalar register pair, and the builtin hands it over.  (HIP's __ballot(int) and __any(int) first
+// turn the condition into a 0/1 integer per lane and compare that again: two half-rate vector
+// instructions per vote, a dozen votes per pass.)
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 // Per-lane tally of the work a scan executes, kept only by the counting build of the trace kernel
 // (RT_OPT_COUNT_WORK); everywhere else the pointer is a compile-time null and the code vanishes.
 struct WorkCount {

@@ -99,7 +99,7 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
 {
     if (!walking)
         node = kBvhDone;
-    const uint32_t n_start = (uint32_t)__popcll(__ballot(walking));
+    const uint32_t n_start = (uint32_t)__popcll(wave_ballot(walking));
     if (n_start == 0u)
         return;
     const uint32_t suspend = n_start > b.suspend_lanes ? b.suspend_lanes : 0u;
@@ -136,7 +136,7 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
     float t_hi = closest * (1.0f + 0x1p-20f);
 
     constexpr int kDone = kBvhDone;
-    while ((uint32_t)__popcll(__ballot(node != kDone)) > suspend) {
+    while ((uint32_t)__popcll(wave_ballot(node != kDone)) > suspend) {
         while (node >= 0) {
             if (wc)
                 ++wc->nodes;

@@ -80,7 +80,7 @@ __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixe
         z = range_m1_p1(w[2]);
         need = !(((x * x) + (y * y) + (z * z)) < 1.0f);
     }
-    unsigned long long nm = __ballot(need);
+    unsigned long long nm = wave_ballot(need);
     while (nm != 0ull) {
         const uint32_t n = (uint32_t)__popcll(nm);
         uint32_t lg = 31u - (uint32_t)__builtin_clz(64u / n);
@@ -105,7 +105,7 @@ __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixe
             hz = range_m1_p1(w[2]);
             ok = ((hx * hx) + (hy * hy) + (hz * hz)) < 1.0f;
         }
-        const unsigned long long okm = __ballot(ok);
+        const unsigned long long okm = wave_ballot(ok);
         __builtin_amdgcn_wave_barrier();
         uint32_t src = (uint32_t)lane;
         bool got = false;
@@ -127,7 +127,7 @@ __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixe
         if (got) {
             x = gx; y = gy; z = gz;
         }
-        nm = __ballot(need);
+        nm = wave_ballot(need);
     }
 }
 
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
 
     for (;;) {
         // ---- refill idle lanes from the wave's chunk, pulling new chunks as needed
-        unsigned long long need = __ballot(!active);
+        unsigned long long need = wave_ballot(!active);
         while (need != 0ull && !queue_empty) {
             if (w_next >= w_end) {
                 const ConstArgs kq = fresh_args(); // the call's shape is needed once per chunk: not worth registers
@@ -375,12 +375,12 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             const uint32_t whole = (uint32_t)(((float)w_pix + 0.5f) * w_inv_npx);
             w_smp += whole;
             w_pix -= __umul24(whole, (uint32_t)ch_npx);
-            need &= ~__ballot(got);
+            need &= ~wave_ballot(got);
         }
 
         RT_CLOCK(wc, kTimeRefill, t_mark);
         // ---- termination
-        const bool wave_active = __any(active);
+        const bool wave_active = wave_any(active);
         if (MULTI_TILE) {
             if (lane == 0)
                 wave_flags[wave] = wave_active ? 1u : 0u;
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             material = a.spheres[best].material;
         const bool wants_point = material == RT_MAT_DIFFUSE || material == RT_MAT_METAL;
         float rx = 0.0f, ry = 0.0f, rz = 0.0f;
-        if (__any(wants_point))
+        if (wave_any(wants_point))
             unit_sphere_points_wave(wants_point, pixel, sample, call, a.key0, a.key1, coop, lane, rx, ry, rz, wc);
 
         RT_CLOCK(wc, kTimePoints, t_mark);
@@ -619,9 +619,9 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
 
         RT_CLOCK(wc, kTimeShade, t_mark);
         // ---- chunks whose last path has just terminated: add their sums to the frame
-        const unsigned long long term = __ballot(terminated);
+        const unsigned long long term = wave_ballot(terminated);
         if (term != 0ull) {
-            const unsigned long long term1 = __ballot(terminated && acc_at >= 192u);
+            const unsigned long long term1 = wave_ballot(terminated && acc_at >= 192u);
             s_done1 += (uint32_t)__popcll(term1);
             s_done0 += (uint32_t)__popcll(term & ~term1);
 #pragma unroll
