@@ -69,7 +69,7 @@ FLOP_PER_ROOT = 6.0           # negate, subtract, sqrt, divide, two range compar
 PEAK_FP32_TFLOPS = 157.3      # 256 CU x 128 FMA lanes x 2 flop x 2.4 GHz (matrix f32 = vector f32 on gfx950)
 PEAK_VALU_TLANEOPS = 78.6     # 256 CU x 4 SIMD x 32 lanes per clock x 2.4 GHz: one wave64 instruction per 2 cycles
 # rocprofv3 evidence of this build's `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`
-PROFILE_DIR = os.path.join("profiles", "r02_start")
+PROFILE_DIR = os.path.join("profiles", "r02_final")
 
 
 def cpu_baseline(scene):
