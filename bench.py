@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="N > 1: nccl = RCCL, one GPU per rank (the measured configuration); gloo = rehearsal of the N > 1 "
                          "path on fewer GPUs than ranks (ranks share devices, exchanged buffers go through the host)")
+    ap.add_argument("--exchange-alone", action="store_true",
+                    help="N = 1: run the N > 1 path's pack / collective / unpack steps over a one-rank RCCL communicator "
+                         "(exercises that path on a one-GPU machine; not the N = 1 measurement)")
     ap.add_argument("--scan", choices=sorted(SCANS), default="auto",
                     help="how rays find their candidate spheres (all give the same frame); auto = the library's choice")
     args = ap.parse_args()
@@ -159,7 +162,11 @@ def main():
     rehearsal = world > 1 and args.backend == "gloo"
     device_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     torch.cuda.set_device(device_index)
-    if world > 1:
+    alone = world == 1 and args.exchange_alone
+    if alone:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)
+    if world > 1 or alone:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -203,11 +210,11 @@ def main():
 
     timed = TimedTracer()
     pipe = dist_render.FramePipeline(timed, p, (W, H, total_spp), args.partition, rank, world, dist, torch, "cuda",
-                                     host_exchange=rehearsal)
+                                     host_exchange=rehearsal, always_exchange=alone)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or alone:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -234,7 +241,7 @@ def main():
     elapsed, kernel_ms, st = run_leg(args.steps, args.warmup)
 
     # ---- second leg and counting launches (one GPU only: they are about the kernels, not the exchange)
-    extra = world == 1 and not args.no_extra_legs and N_SPHERES <= 2000
+    extra = world == 1 and not alone and not args.no_extra_legs and N_SPHERES <= 2000
     list_leg = counted = None
     if extra:
         def count_work(filt):
@@ -256,11 +263,11 @@ def main():
             counted["matrix"] = count_work(rtamd.FILTER_MATRIX)
         ctx.set_option(rtamd.OPT_FILTER, SCANS[args.scan])
 
-    if world > 1:
+    if world > 1 or alone:
         dist.barrier()
     t = torch.tensor([elapsed, float(st.rays), float(st.wave_passes), kernel_ms], dtype=torch.float64,
                      device="cpu" if rehearsal else "cuda")
-    if world > 1:
+    if world > 1 or alone:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -276,7 +283,7 @@ def main():
         kernel_s = kernel_ms * 1e-3
         ref_equiv = rays_per_launch * N_SPHERES * FLOP_PER_TEST / kernel_s / 1e12
         collective = "none"
-        if world > 1:
+        if world > 1 or alone:
             collective = ("gather(uint8, %d bytes per rank) to rank 0" % pipe.block_bytes if args.partition == "tiles"
                           else "reduce(sum, int32, %d) to rank 0" % (W * H * 3))
         line = {
@@ -291,11 +298,12 @@ def main():
             "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL over gloo: ranks share GPUs, not a measurement)",
+            "data": ("synthetic (REHEARSAL over gloo: ranks share GPUs, not a measurement)" if rehearsal else
+                     "synthetic (one rank running the N > 1 exchange path, not the N = 1 measurement)" if alone else "synthetic"),
             "config": {
                 "workload": WORKLOAD_TEXT[args.workload] + (" per GPU (weak scaling)" if world > 1 and args.scaling == "weak" else ""),
                 "spheres": N_SPHERES, "width": W, "height": H, "frame_spp": total_spp,
-                "max_depth": DEPTH, "partition": args.partition if world > 1 else "none (one GPU)", "scan": scan,
+                "max_depth": DEPTH, "partition": args.partition if world > 1 or alone else "none (one GPU)", "scan": scan,
                 "collective": collective,
                 "overlap": "exchange of frame k runs beside the tracing of frame k + 1" if world > 1 else "none",
             },
@@ -377,7 +385,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     ctx.close()
-    if world > 1:
+    if world > 1 or alone:
         dist.destroy_process_group()
 
 

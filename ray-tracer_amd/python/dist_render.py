@@ -92,17 +92,20 @@ class FramePipeline:
     rotate; slot s's RGB8 frame is `rgb[s]` on rank 0.  With world == 1 there is no exchange.
 
     host_exchange=True stages the exchanged tensors through host memory (for backends that cannot
-    move device tensors, i.e. the gloo tests on one GPU).
+    move device tensors, i.e. the gloo tests on one GPU).  always_exchange=True runs the pack /
+    collective / unpack steps with world == 1 too (a one-rank communicator): the N > 1 code path on a
+    one-GPU machine.
     """
 
     def __init__(self, tracer, params, shape, partition, rank, world, dist, torch, device, slots=2,
-                 host_exchange=False):
+                 host_exchange=False, always_exchange=False):
         """`params` = rank_params(...) of this rank (None: nothing to trace); `shape` = (width, height,
         frame spp); `partition` = "samples" or "tiles"."""
         p = params
         self.tracer, self.p, self.rank, self.world, self.dist, self.torch = tracer, p, rank, world, dist, torch
         self.host_exchange = host_exchange
-        self.tiles = world > 1 and partition == "tiles"
+        self.exchange = world > 1 or always_exchange
+        self.tiles = self.exchange and partition == "tiles"
         self.slots = slots
         self.submitted = 0
         self.pending = None  # (slot, work handle) of the frame not yet completed
@@ -151,7 +154,7 @@ class FramePipeline:
         if self.p is not None:
             self.tracer.accumulate(self.p, self.sums[s])
         work = _Done()
-        if self.world > 1:
+        if self.exchange:
             if self.tiles:
                 self.tracer.pack_tiles(self.sums[s], w, h, spp, self.rank, self.world, self.block[s])
                 work, _ = self._gather_blocks(s)

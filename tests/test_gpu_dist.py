@@ -1,6 +1,7 @@
 """Two processes, one device each in production; here both on GPU 0 with gloo carrying the reduce
 (RCCL needs one device per rank).  The real library traces each rank's share; the assembled frame
-must equal the single-process frame and the oracle's, for both partitionings."""
+must equal the single-process frame and the oracle's, for both partitionings.  RCCL itself runs as a
+one-rank communicator: the same pack / collective / unpack calls on device tensors."""
 import os
 import socket
 import sys
@@ -98,3 +99,64 @@ def test_bench_multi_rank_path_rehearsed_on_one_gpu(extra, rays):
     else:
         assert line["scaling"] == "weak" and line["config"]["frame_spp"] == 128 and line["rays_per_step"] > 2 * 301000000
     assert line["value"] > 0 and line["ms_per_step"] > 0
+
+
+def _rccl_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+
+    import dist_render
+    import rtamd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    ctx = rtamd.Context(0)
+    ctx.set_scene(scenes.random_spheres(500))
+    tracer = dist_render.DeviceTracer(ctx, rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA))
+    frames = []
+    for partition in ("samples", "tiles"):
+        p = dist_render.rank_params(W, H, SPP, DEPTH, SEED, partition, rank, world)
+        pipe = dist_render.FramePipeline(tracer, p, (W, H, SPP), partition, rank, world, dist, torch, "cuda", slots=2,
+                                         always_exchange=True)
+        for _ in range(3):
+            pipe.submit()
+        pipe.finish()
+        torch.cuda.synchronize()
+        dist.barrier()
+        frames.append(torch.stack(pipe.rgb).cpu().numpy().reshape(2, H, W, 3))
+    np.save(out_path, np.stack(frames))
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_exchange_path_over_a_one_rank_rccl_communicator(tmp_path):
+    """The device-tensor exchange (async reduce of the int32 sums, async gather of the tile blocks,
+    barrier) through RCCL itself, with the one rank a one-GPU machine allows."""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "rccl.npy")
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    got = np.load(out)
+    sc = scenes.random_spheres(500)
+    want, _, _ = O.trace_tile(sc, O.camera(*scenes.RANDOM_SPHERES_CAMERA), W, H, SPP, DEPTH, O.RNG_COUNTER, seed=SEED)
+    for part in range(2):
+        for slot in range(2):
+            assert np.array_equal(got[part, slot], want)
+
+
+@pytest.mark.parametrize("partition", ["tiles", "samples"])
+def test_bench_exchange_path_alone_over_rccl(partition):
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--exchange-alone",
+           "--partition", partition, "--no-cpu-baseline"]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=280, cwd=root, env=env).stdout
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["rays_per_step"] == 301321686
+    assert line["config"]["partition"] == partition and "not the N = 1 measurement" in line["data"]
+    assert ("gather" if partition == "tiles" else "reduce") in line["config"]["collective"]
