@@ -590,8 +590,10 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 }
                 active = false;
             } else if (terminated) {
-                // unwind the recursion: per level, bytes -> float -> bytes (:569-578, :587-591)
-                for (int l = level - 1; l >= 0; --l) {
+                // unwind the recursion: per level, bytes -> float -> bytes (:569-578, :587-591).  Black
+                // stays black at every level (ToRGB of Color * 0, or of NaN for a non-finite Color, is 0),
+                // so the paths that ran out of depth -- the longest stacks -- have nothing to unwind.
+                for (int l = (cr | cg | cb) != 0 ? level - 1 : -1; l >= 0; --l) {
                     const rt_sphere *sp = a.spheres + read_bounce(stack, a.stack_entry_bytes, l * kTraceThreads + tid);
                     RT_TALLY(wc, kSecReplayLevel);
                     if (sp->material == RT_MAT_DIFFUSE) {
