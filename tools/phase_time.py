@@ -1,5 +1,5 @@
 """Where a wave's lifetime goes, phase by phase (counting build, s_memtime stamps), for a few call shapes.
-Usage: python tools/phase_time.py   (on a GPU box)"""
+Usage: python tools/phase_time.py [hierarchy|matrix|vector]   (on a GPU box)"""
 import os
 import sys
 
@@ -11,6 +11,8 @@ import scenes
 
 ctx = rtamd.Context(0)
 ctx.set_scene(scenes.random_spheres(500))
+ctx.set_option(rtamd.OPT_FILTER, {"hierarchy": rtamd.FILTER_BVH, "matrix": rtamd.FILTER_MATRIX, "vector": rtamd.FILTER_CONSERVATIVE}[
+    sys.argv[1] if len(sys.argv) > 1 else "hierarchy"])
 ctx.set_option(rtamd.OPT_COUNT_WORK, 1)
 cam = rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA)
 d = torch.zeros(1920 * 1080 * 3, dtype=torch.int32, device="cuda")

@@ -1,6 +1,7 @@
 """Where the hierarchy kernel's waves spend their passes: per section of the kernel, how often a wave
 executed it per pass and with how many of its 64 lanes enabled (counting build, RT_OPT_COUNT_WORK).
-Usage: python tools/work_profile.py [scan]   (on a GPU box; bench frame: 1080p, 64 spp, depth 8, 500 spheres)"""
+Usage: python tools/work_profile.py [scan [spheres]]   (on a GPU box; bench frame: 1080p, 64 spp, depth 8,
+500 spheres unless given; 10000 = the 10k-sphere configuration)"""
 import os
 import sys
 
@@ -13,7 +14,8 @@ import scenes
 scan = {"hierarchy": rtamd.FILTER_BVH, "matrix": rtamd.FILTER_MATRIX, "vector": rtamd.FILTER_CONSERVATIVE}[
     sys.argv[1] if len(sys.argv) > 1 else "hierarchy"]
 ctx = rtamd.Context(0)
-ctx.set_scene(scenes.random_spheres(500))
+n_spheres = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+ctx.set_scene(scenes.random_spheres(n_spheres, grid_half=50 if n_spheres > 2000 else 11))
 ctx.set_option(rtamd.OPT_FILTER, scan)
 ctx.set_option(rtamd.OPT_COUNT_WORK, 1)
 cam = rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA)
