@@ -14,6 +14,8 @@ ctx.set_scene(scenes.random_spheres(500))
 ctx.set_option(rtamd.OPT_FILTER, {"hierarchy": rtamd.FILTER_BVH, "matrix": rtamd.FILTER_MATRIX, "vector": rtamd.FILTER_CONSERVATIVE}[
     sys.argv[1] if len(sys.argv) > 1 else "hierarchy"])
 ctx.set_option(rtamd.OPT_COUNT_WORK, 1)
+if os.environ.get("PT_WG_PER_CU"):  # e.g. 1: one wave per SIMD, nothing hides a phase's latencies
+    ctx.set_option(rtamd.OPT_WORKGROUPS_PER_CU, int(os.environ["PT_WG_PER_CU"]))
 cam = rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA)
 d = torch.zeros(1920 * 1080 * 3, dtype=torch.int32, device="cuda")
 for W, H, spp, depth in ((1920, 1080, 1, 1), (1920, 1080, 1, 8), (1920, 1080, 4, 8), (1920, 1080, 64, 8)):
