@@ -245,7 +245,8 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out);
  * the transport: RT_EXCHANGE_RCCL (ncclReduce / grouped ncclSend+ncclRecv; librccl is loaded with
  * dlopen by this call), RT_EXCHANGE_PEER_COPY (the first device adds the others' sums in place over
  * xGMI peer access, tile blocks are copied device to device), RT_EXCHANGE_AUTO (RCCL if it loads
- * and all ids are distinct, else peer copies).  The same id may appear several times (ranks sharing
+ * and all ids are distinct, else peer copies; creation fails with RT_ERR_HIP when neither transport
+ * exists between the first device and another one).  The same id may appear several times (ranks sharing
  * a device exchange by peer copies; meant for testing on one GPU).  At most 16 entries.
  * Frames are double-buffered: rt_multi_render_device returns when the frame is enqueued, and the
  * exchange of one frame runs beside the tracing of the next. */

@@ -309,6 +309,7 @@ int rt_multi_create(const int *device_ids, uint32_t n_devices, int exchange, rt_
                 st = RT_ERR_HIP;
     }
     // the first device reads (peer copies) or receives (RCCL) the others' memory
+    bool all_peers = true; // the first device can address every other rank's memory
     for (uint32_t i = 1; i < n_devices && st == RT_OK; ++i) {
         if (m->ranks[i].device == m->ranks[0].device)
             continue;
@@ -319,8 +320,10 @@ int rt_multi_create(const int *device_ids, uint32_t n_devices, int exchange, rt_
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
                 st = RT_ERR_HIP;
             (void)hipGetLastError();
-        } else if (exchange == RT_EXCHANGE_PEER_COPY) {
-            st = RT_ERR_HIP; // no peer path between the devices
+        } else {
+            all_peers = false;
+            if (exchange == RT_EXCHANGE_PEER_COPY)
+                st = RT_ERR_HIP; // no peer path between the devices
         }
     }
     if (st == RT_OK && distinct && exchange != RT_EXCHANGE_PEER_COPY) {
@@ -339,6 +342,9 @@ int rt_multi_create(const int *device_ids, uint32_t n_devices, int exchange, rt_
             st = RT_ERR_HIP;
         }
     }
+    // without RCCL the first device's add kernel and copies read the other devices' buffers in place
+    if (st == RT_OK && !m->use_rccl && !all_peers)
+        st = RT_ERR_HIP;
     if (st != RT_OK) {
         rt_multi_destroy(m);
         return st;
