@@ -190,12 +190,13 @@ __device__ __forceinline__ double divide_by_reciprocal(double a, double b, doubl
 
 // u, v of Source/main.cpp:627-628 (double sums and quotients, narrowed to float) and Camera::GetRay
 // (:440-444).  inv_width / inv_height are 1/(double)(float)width and height, rounded on the host.
-__device__ __forceinline__ void camera_ray(const rt_camera &cam, uint32_t width, uint32_t height,
+// width_d / height_d are (double)(float)width and height.
+__device__ __forceinline__ void camera_ray(const rt_camera &cam, double width_d, double height_d,
                                            double inv_width, double inv_height,
                                            int i, int j, double ju, double jv, RayState &r)
 {
-    const float u = (float)divide_by_reciprocal((double)(float)i + ju, (double)(float)width, inv_width);
-    const float v = (float)divide_by_reciprocal((double)(float)j + jv, (double)(float)height, inv_height);
+    const float u = (float)divide_by_reciprocal((double)(float)i + ju, width_d, inv_width);
+    const float v = (float)divide_by_reciprocal((double)(float)j + jv, height_d, inv_height);
     r.ox = cam.origin[0]; r.oy = cam.origin[1]; r.oz = cam.origin[2];
     r.dx = ((cam.bottom_left[0] + (cam.horizontal[0] * u)) + (v * cam.vertical[0])) - cam.origin[0];
     r.dy = ((cam.bottom_left[1] + (cam.horizontal[1] * u)) + (v * cam.vertical[1])) - cam.origin[1];

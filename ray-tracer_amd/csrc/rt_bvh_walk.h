@@ -85,8 +85,17 @@ __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, f
     closest = INFINITY;
     best = -1;
     RT_TALLY(wc, kSecWalkBegin);
-    for (uint32_t i = 0; i < b.n_large; ++i)
-        resolve_unordered(r, b.leaf_geom[i], (int)b.leaf_index[i], tmin, closest, best, wc);
+    // the same records for every lane, never written while a kernel runs: read with scalar loads
+    // (constant address space) instead of one vector load per lane and sphere
+    typedef const __attribute__((address_space(4))) float *ConstFloats;
+    typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
+    const ConstFloats lg = (ConstFloats)b.leaf_geom;
+    const ConstWords li = (ConstWords)b.leaf_index;
+    for (uint32_t i = 0; i < b.n_large; ++i) {
+        Geom g;
+        g.cx = lg[4u * i + 0u]; g.cy = lg[4u * i + 1u]; g.cz = lg[4u * i + 2u]; g.r2 = lg[4u * i + 3u];
+        resolve_unordered(r, g, (int)li[i], tmin, closest, best, wc);
+    }
     node = b.n_nodes ? 0 : kBvhDone;
     sp = 0u;
 }
@@ -116,21 +125,25 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
 
     const float dmax = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz));
     const float dlim = dmax * 0x1p-50f;
-    const float ddx = fabsf(r.dx) < dlim ? copysignf(dlim, r.dx) : r.dx;
-    const float ddy = fabsf(r.dy) < dlim ? copysignf(dlim, r.dy) : r.dy;
-    const float ddz = fabsf(r.dz) < dlim ? copysignf(dlim, r.dz) : r.dz;
+    const float ddx = copysignf(fmaxf(fabsf(r.dx), dlim), r.dx);
+    const float ddy = copysignf(fmaxf(fabsf(r.dy), dlim), r.dy);
+    const float ddz = copysignf(fmaxf(fabsf(r.dz), dlim), r.dz);
     const float ix = __builtin_amdgcn_rcpf(ddx), iy = __builtin_amdgcn_rcpf(ddy), iz = __builtin_amdgcn_rcpf(ddz);
-    // t at plane p: (p - o) / d = fma(p, i, n); lower planes are moved by -pad, upper by +pad
-    const float nlx = -((ox + pad) * ix), nly = -((oy + pad) * iy), nlz = -((oz + pad) * iz);
-    const float nhx = -((ox - pad) * ix), nhy = -((oy - pad) * iy), nhz = -((oz - pad) * iz);
+    // t at plane p: (p - o) / d = fma(p, i, -o i).  The box is padded, so the plane the ray meets
+    // first lies pad further back and the one it meets last pad further on, whichever way it runs:
+    // the entry planes' constant is -o i - pad |i|, the exit planes' -o i + pad |i| (a product and a
+    // fused multiply-add each: two roundings of relative size u on |o i| + pad |i|, as counted above).
+    const float mx = -(ox * ix), my = -(oy * iy), mz = -(oz * iz);
+    const float ncx = __builtin_fmaf(-pad, fabsf(ix), mx), fcx = __builtin_fmaf(pad, fabsf(ix), mx);
+    const float ncy = __builtin_fmaf(-pad, fabsf(iy), my), fcy = __builtin_fmaf(pad, fabsf(iy), my);
+    const float ncz = __builtin_fmaf(-pad, fabsf(iz), mz), fcz = __builtin_fmaf(pad, fabsf(iz), mz);
     // Which of the two planes of an axis the ray meets first depends on the sign of d.  Instead
     // of min/max per box (half-rate instructions), each t is fma(lo, a, fma(hi, b, c)) with one
     // of a, b zero: the same single rounding, on full-rate instructions only.
-    const bool px = ix >= 0.0f, py = iy >= 0.0f, pz = iz >= 0.0f;
     // entry plane: fma(lo, na, fma(hi, nb, nc)); exit plane: the same with na and nb swapped
-    const float nax = px ? ix : 0.0f, nbx = ix - nax, ncx = px ? nlx : nhx, fcx = px ? nhx : nlx;
-    const float nay = py ? iy : 0.0f, nby = iy - nay, ncy = py ? nly : nhy, fcy = py ? nhy : nly;
-    const float naz = pz ? iz : 0.0f, nbz = iz - naz, ncz = pz ? nlz : nhz, fcz = pz ? nhz : nlz;
+    const float nax = fmaxf(ix, 0.0f), nbx = ix - nax;
+    const float nay = fmaxf(iy, 0.0f), nby = iy - nay;
+    const float naz = fmaxf(iz, 0.0f), nbz = iz - naz;
     const float fax = nbx, fbx = nax, fay = nby, fby = nay, faz = nbz, fbz = naz;
     const float t_lo = tmin * (1.0f - 0x1p-20f);
     float t_hi = closest * (1.0f + 0x1p-20f);

@@ -351,8 +351,10 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     a.cam = *cam;
     a.width = p->width;
     a.height = p->height;
-    a.inv_width = 1.0 / (double)(float)p->width;
-    a.inv_height = 1.0 / (double)(float)p->height;
+    a.width_d = (double)(float)p->width;
+    a.height_d = (double)(float)p->height;
+    a.inv_width = 1.0 / a.width_d;
+    a.inv_height = 1.0 / a.height_d;
     a.sample_begin = p->sample_begin;
     a.sample_count = p->sample_count ? p->sample_count : p->spp;
     a.max_depth = p->max_depth;

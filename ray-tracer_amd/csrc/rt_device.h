@@ -70,6 +70,7 @@ struct TraceArgs {
     rt_camera cam;
     uint32_t width, height;
     double inv_width, inv_height; // 1/(double)(float)width, 1/(double)(float)height, correctly rounded
+    double width_d, height_d;     // (double)(float)width, (double)(float)height
     uint32_t sample_begin, sample_count;
     int32_t max_depth;
     uint32_t flags;            // RT_FLAG_*

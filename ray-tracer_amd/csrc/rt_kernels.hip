@@ -83,7 +83,9 @@ __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixe
     unsigned long long nm = wave_ballot(need);
     while (nm != 0ull) {
         const uint32_t n = (uint32_t)__popcll(nm);
-        uint32_t lg = 31u - (uint32_t)__builtin_clz(64u / n);
+        // per = the largest power of two with per * n <= 64, at most 16: log2(per) = 6 - ceil(log2(n)),
+        // in scalar bit operations (a division here would run on the vector ALU)
+        uint32_t lg = 6u - (n > 1u ? 32u - (uint32_t)__builtin_clz(n - 1u) : 0u);
         lg = lg > 4u ? 4u : lg;
         const uint32_t per = 1u << lg;
         const uint32_t k = lane_rank(nm);
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                     cam.horizontal[q] = ka->cam.horizontal[q];
                     cam.vertical[q] = ka->cam.vertical[q];
                 }
-                camera_ray(cam, ka->width, ka->height, ka->inv_width, ka->inv_height, px, py, (double)unit_float(w[0]),
+                camera_ray(cam, ka->width_d, ka->height_d, ka->inv_width, ka->inv_height, px, py, (double)unit_float(w[0]),
                            (double)unit_float(w[1]), ray);
                 depth = a.max_depth; // >= 1: the host does not launch for RAY_DEPTH <= 0
                 level = 0;
@@ -799,7 +801,7 @@ __global__ void __launch_bounds__(256) primary_hits_kernel(const HitsArgs a, uin
 
     RayState ray = {};
     if (inside)
-        camera_ray(a.cam, a.width, a.height, a.inv_width, a.inv_height, px, py, 0.5, 0.5, ray);
+        camera_ray(a.cam, (double)(float)a.width, (double)(float)a.height, a.inv_width, a.inv_height, px, py, 0.5, 0.5, ray);
 
     float closest = INFINITY;
     int best = -1;
