@@ -57,19 +57,17 @@ int walk(const BvhHost &b, const Ray &r, float tmin, float *t_out)
         const float pad = fmaf(reff, 0x1.01p-10f, reff - b.rmin) * 1.001f;
         const float dmax = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz));
         const float dlim = dmax * 0x1p-50f;
-        const float dd[3] = { fabsf(r.dx) < dlim ? copysignf(dlim, r.dx) : r.dx,
-                              fabsf(r.dy) < dlim ? copysignf(dlim, r.dy) : r.dy,
-                              fabsf(r.dz) < dlim ? copysignf(dlim, r.dz) : r.dz };
+        const float dd[3] = { copysignf(fmaxf(fabsf(r.dx), dlim), r.dx), copysignf(fmaxf(fabsf(r.dy), dlim), r.dy),
+                              copysignf(fmaxf(fabsf(r.dz), dlim), r.dz) };
         const float o[3] = { ox, oy, oz };
         float na[3], nb[3], nc[3], fc[3];
         for (int k = 0; k < 3; ++k) {
             const float inv = 1.0f / dd[k];
-            const float nl = -((o[k] + pad) * inv), nh = -((o[k] - pad) * inv);
-            const bool pos = inv >= 0.0f;
-            na[k] = pos ? inv : 0.0f;
+            const float m = -(o[k] * inv);
+            na[k] = fmaxf(inv, 0.0f);
             nb[k] = inv - na[k];
-            nc[k] = pos ? nl : nh;
-            fc[k] = pos ? nh : nl;
+            nc[k] = fmaf(-pad, fabsf(inv), m);
+            fc[k] = fmaf(pad, fabsf(inv), m);
         }
         const float t_lo = tmin * (1.0f - 0x1p-20f);
         std::vector<int> stack;
