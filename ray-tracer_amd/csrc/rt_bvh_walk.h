@@ -41,6 +41,43 @@ __device__ __forceinline__ void leaf_root(const RayState &r, float B, float disc
     }
 }
 
+// The reference's exact test for records [first, first + count) of the leaf-ordered list, four at
+// a time: up to four records in flight before the first is used, their discriminants as one block
+// of independent arithmetic (all four unconditionally -- the record array ends in three records of
+// padding -- and the bits of records beyond `count` dropped afterwards); then every lane walks its
+// own candidates, so the wave pays for the most candidates any lane has, not for every record some
+// lane hits.
+__device__ __forceinline__ void test_records(const BvhArgs &b, const RayState &r, uint32_t first, uint32_t count,
+                                             float tmin, float &closest, int &best, WorkCount *wc)
+{
+    for (uint32_t i0 = 0u; i0 < count; i0 += 4u) {
+        Geom g[4];
+        RT_TALLY(wc, kSecLeafGroup);
+#pragma unroll
+        for (uint32_t j = 0u; j < 4u; ++j)
+            g[j] = b.leaf_geom[first + i0 + j];
+        float Bj[4], dj[4];
+        uint32_t cand = 0u;
+#pragma unroll
+        for (uint32_t j = 0u; j < 4u; ++j)
+            if (leaf_candidate(r, g[j], Bj[j], dj[j]))
+                cand |= 1u << j;
+        cand &= (1u << min(4u, count - i0)) - 1u;
+        if (wc) {
+            wc->exact += min(4u, count - i0);
+            wc->roots += (uint32_t)__popc(cand);
+        }
+        while (cand != 0u) {
+            const uint32_t j = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1u;
+            RT_TALLY(wc, kSecRoot);
+            const float Bs = j == 0u ? Bj[0] : j == 1u ? Bj[1] : j == 2u ? Bj[2] : Bj[3];
+            const float ds = j == 0u ? dj[0] : j == 1u ? dj[1] : j == 2u ? dj[2] : dj[3];
+            leaf_root(r, Bs, ds, b.leaf_index + (first + i0 + j), tmin, closest, best);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Hierarchy scan: a per-ray walk over boxes instead of a pass over the list
 // ---------------------------------------------------------------------------
@@ -186,38 +223,8 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
         }
         if (node == kDone)
             continue;
-        const uint32_t code = (uint32_t)~node, first = code >> 4, count = code & 15u;
-        for (uint32_t i0 = 0u; i0 < count; i0 += 4u) {
-            // up to four records in flight before the first is used; then every lane walks its
-            // own candidates, so the wave pays for the most candidates any lane has, not for
-            // every record some lane hits
-            Geom g[4];
-            RT_TALLY(wc, kSecLeafGroup);
-#pragma unroll
-            for (uint32_t j = 0u; j < 4u; ++j)
-                if (i0 + j < count)
-                    g[j] = b.leaf_geom[first + i0 + j];
-            float Bj[4], dj[4];
-            uint32_t cand = 0u;
-#pragma unroll
-            for (uint32_t j = 0u; j < 4u; ++j) {
-                Bj[j] = dj[j] = 0.0f;
-                if (i0 + j < count && leaf_candidate(r, g[j], Bj[j], dj[j]))
-                    cand |= 1u << j;
-            }
-            if (wc) {
-                wc->exact += min(4u, count - i0);
-                wc->roots += (uint32_t)__popc(cand);
-            }
-            while (cand != 0u) {
-                const uint32_t j = (uint32_t)__builtin_ctz(cand);
-                cand &= cand - 1u;
-                RT_TALLY(wc, kSecRoot);
-                const float Bs = j == 0u ? Bj[0] : j == 1u ? Bj[1] : j == 2u ? Bj[2] : Bj[3];
-                const float ds = j == 0u ? dj[0] : j == 1u ? dj[1] : j == 2u ? dj[2] : dj[3];
-                leaf_root(r, Bs, ds, b.leaf_index + (first + i0 + j), tmin, closest, best);
-            }
-        }
+        const uint32_t code = (uint32_t)~node;
+        test_records(b, r, code >> 4, code & 15u, tmin, closest, best, wc);
         t_hi = closest * (1.0f + 0x1p-20f);
         if (sp == 0u) {
             node = kDone;

@@ -264,7 +264,8 @@ int ensure_bvh(rt_context *ctx)
     if (!why.empty())
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "hierarchy failed its structural check: " + why);
     const size_t nb = std::max<size_t>(b.nodes.size(), 1) * sizeof(BvhNode);
-    const size_t gb = std::max<size_t>(b.leaf_geom.size(), 1) * sizeof(Geom);
+    // three records of padding: the walk reads a leaf's records four at a time
+    const size_t gb = (b.leaf_geom.size() + 3u) * sizeof(Geom);
     const size_t ib = std::max<size_t>(b.leaf_index.size(), 1) * sizeof(uint32_t);
     if (hipMalloc((void **)&ctx->d_bvh_nodes, nb) != hipSuccess || hipMalloc((void **)&ctx->d_bvh_geom, gb) != hipSuccess ||
         hipMalloc((void **)&ctx->d_bvh_index, ib) != hipSuccess) {
@@ -273,6 +274,7 @@ int ensure_bvh(rt_context *ctx)
     }
     if (!b.nodes.empty())
         RT_HIP(ctx, hipMemcpy(ctx->d_bvh_nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemset(ctx->d_bvh_geom, 0, gb));
     if (!b.leaf_geom.empty()) {
         RT_HIP(ctx, hipMemcpy(ctx->d_bvh_geom, b.leaf_geom.data(), b.leaf_geom.size() * sizeof(Geom), hipMemcpyHostToDevice));
         RT_HIP(ctx, hipMemcpy(ctx->d_bvh_index, b.leaf_index.data(), b.leaf_index.size() * sizeof(uint32_t),

@@ -46,7 +46,7 @@ enum {
 // Device view of the hierarchy (see rt_bvh.h for the encoding).
 struct BvhArgs {
     const float4 *nodes;        // four float4 per node
-    const Geom *leaf_geom;      // n_large always-tested records, then the leaves' records
+    const Geom *leaf_geom;      // n_large always-tested records, then the leaves' records, then 3 of padding
     const uint32_t *leaf_index; // list index of each record
     uint32_t n_nodes, n_large;
     uint32_t levels;            // traversal stack entries per ray (>= 1)
