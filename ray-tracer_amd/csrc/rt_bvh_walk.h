@@ -115,6 +115,15 @@ __device__ __forceinline__ void test_records(const BvhArgs &b, const RayState &r
 // node: >= 0 inner node to visit, negative leaf code to process, kBvhDone when finished.
 constexpr int kBvhDone = INT_MIN;
 
+// max(|x|, m) in one instruction (written with fmaxf and fabsf, the compiler first spends one to
+// canonicalise |x|).
+__device__ __forceinline__ float max_abs(float x, float m)
+{
+    float o;
+    asm("v_max_f32_e64 %0, |%1|, %2" : "=v"(o) : "v"(x), "v"(m));
+    return o;
+}
+
 // Start of a ray's walk: the always-tested spheres, then the root.
 __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, float tmin, int &node, uint32_t &sp,
                                           float &closest, int &best, WorkCount *wc = nullptr)
@@ -162,9 +171,9 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
 
     const float dmax = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz));
     const float dlim = dmax * 0x1p-50f;
-    const float ddx = copysignf(fmaxf(fabsf(r.dx), dlim), r.dx);
-    const float ddy = copysignf(fmaxf(fabsf(r.dy), dlim), r.dy);
-    const float ddz = copysignf(fmaxf(fabsf(r.dz), dlim), r.dz);
+    const float ddx = copysignf(max_abs(r.dx, dlim), r.dx);
+    const float ddy = copysignf(max_abs(r.dy, dlim), r.dy);
+    const float ddz = copysignf(max_abs(r.dz, dlim), r.dz);
     const float ix = __builtin_amdgcn_rcpf(ddx), iy = __builtin_amdgcn_rcpf(ddy), iz = __builtin_amdgcn_rcpf(ddz);
     // t at plane p: (p - o) / d = fma(p, i, -o i).  The box is padded, so the plane the ray meets
     // first lies pad further back and the one it meets last pad further on, whichever way it runs:
