@@ -50,7 +50,7 @@ struct rt_context {
     uint32_t bvh_suspend_lanes = 16;  // see RT_OPT_BVH_SUSPEND_LANES
     uint32_t bvh_lds_nodes_max = 512; // trees up to this many nodes (64 B each) are walked in LDS
     uint32_t subtiles_max = 4;     // work queue: tiles may be cut into this many strips of rows (1, 2 or 4)
-    uint32_t chunks_per_wave = 16; // work queue: split tiles' samples until there are this many chunks per resident wave
+    uint32_t chunks_per_wave = 32; // work queue: split tiles' samples until there are this many chunks per resident wave
     uint32_t direct_add_samples = 1; // RT_OPT_DIRECT_ADD_SAMPLES
     bool count_work = false;       // RT_OPT_COUNT_WORK: launch the counting build of the trace kernel
     uint32_t bvh_auto_min = 64;    // automatic choice: hierarchy from this many spheres up (measured crossover)
