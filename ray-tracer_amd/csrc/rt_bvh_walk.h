@@ -146,20 +146,19 @@ __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, f
     sp = 0u;
 }
 
-// Must be called by all 64 lanes; `walking` lanes hold a tame ray whose node is not kBvhDone.
+// Must be called by all 64 lanes.  The lanes whose node is not kBvhDone walk (they hold a tame ray
+// and the state bvh_begin or an earlier call left); every other lane must hold kBvhDone.
 template <bool NODES_IN_LDS>
 __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nodes, const RayState &r,
-                                         uint32_t *stk, bool walking, float tmin, int &node, uint32_t &sp,
+                                         uint32_t *stk, float tmin, int &node, uint32_t &sp,
                                          float &closest, int &best, WorkCount *wc = nullptr)
 {
-    if (!walking)
-        node = kBvhDone;
-    const uint32_t n_start = (uint32_t)__popcll(wave_ballot(walking));
+    const uint32_t n_start = (uint32_t)__popcll(wave_ballot(node != kBvhDone));
     if (n_start == 0u)
         return;
     const uint32_t suspend = n_start > b.suspend_lanes ? b.suspend_lanes : 0u;
 
-    if (walking)
+    if (node != kBvhDone)
         RT_TALLY(wc, kSecWalkSetup);
     const float ox = r.ox - b.center[0], oy = r.oy - b.center[1], oz = r.oz - b.center[2];
     // reach^2 = (|o| + radius)^2 <= 2 (|o|^2 + radius^2); the hardware square root (1 ulp) is
@@ -258,7 +257,7 @@ __device__ __forceinline__ void closest_hit_by_hierarchy(const BvhArgs &b, const
         else
             scan_tile<kFilterExact>(exact, exact, n, 0u, r, 0.001f, closest, best);
     }
-    bvh_walk<false>(b, nullptr, r, stk, have && node != kBvhDone, 0.001f, node, sp, closest, best);
+    bvh_walk<false>(b, nullptr, r, stk, 0.001f, node, sp, closest, best);
 }
 
 

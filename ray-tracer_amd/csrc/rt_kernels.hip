@@ -70,18 +70,22 @@ __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixe
                                                         uint32_t k0, uint32_t k1, uint32_t *coop, int lane,
                                                         float &x, float &y, float &z, WorkCount *wc = nullptr)
 {
-    bool need = want;
-    if (need) {
+    // Wave votes are taken on comparisons of register values, and the set of lanes still looking
+    // for a point is kept as a lane mask: a vote on a flag that was set under a branch costs two
+    // more vector instructions to bring the flag into that form.
+    float len2 = 0.0f;
+    if (want) {
         uint32_t w[4];
         RT_TALLY(wc, kSecPointFirst);
         philox4x32_10(pixel, sample, call++, k0, k1, w);
         x = range_m1_p1(w[0]);
         y = range_m1_p1(w[1]);
         z = range_m1_p1(w[2]);
-        need = !(((x * x) + (y * y) + (z * z)) < 1.0f);
+        len2 = (x * x) + (y * y) + (z * z);
     }
-    unsigned long long nm = wave_ballot(need);
+    unsigned long long nm = wave_ballot(!(len2 < 1.0f));
     while (nm != 0ull) {
+        const bool need = __builtin_amdgcn_inverse_ballot_w64(nm);
         const uint32_t n = (uint32_t)__popcll(nm);
         // per = the largest power of two with per * n <= 64, at most 16: log2(per) = 6 - ceil(log2(n)),
         // in scalar bit operations (a division here would run on the vector ALU)
@@ -96,8 +100,7 @@ __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixe
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t t = (uint32_t)lane >> lg, at = (uint32_t)lane & (per - 1u);
-        float hx = 0.0f, hy = 0.0f, hz = 0.0f;
-        bool ok = false;
+        float hx = 0.0f, hy = 0.0f, hz = 0.0f, hlen2 = 2.0f;
         if (t < n) {
             uint32_t w[4];
             RT_TALLY(wc, kSecPointHelp);
@@ -105,23 +108,20 @@ __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixe
             hx = range_m1_p1(w[0]);
             hy = range_m1_p1(w[1]);
             hz = range_m1_p1(w[2]);
-            ok = ((hx * hx) + (hy * hy) + (hz * hz)) < 1.0f;
+            hlen2 = (hx * hx) + (hy * hy) + (hz * hz);
         }
-        const unsigned long long okm = wave_ballot(ok);
+        const unsigned long long okm = wave_ballot(hlen2 < 1.0f);
         __builtin_amdgcn_wave_barrier();
-        uint32_t src = (uint32_t)lane;
-        bool got = false;
-        if (need) {
-            const uint32_t bits = (uint32_t)(okm >> (k << lg)) & ((1u << per) - 1u);
-            if (bits != 0u) {
-                const uint32_t first = (uint32_t)__builtin_ctz(bits);
-                src = (k << lg) + first;
-                call += first + 1u;
-                got = true;
-                need = false;
-            } else {
-                call += per;
-            }
+        uint32_t src = (uint32_t)lane, bits = 0u;
+        if (need)
+            bits = (uint32_t)(okm >> (k << lg)) & ((1u << per) - 1u);
+        const bool got = bits != 0u;
+        if (got) {
+            const uint32_t first = (uint32_t)__builtin_ctz(bits);
+            src = (k << lg) + first;
+            call += first + 1u;
+        } else if (need) {
+            call += per;
         }
         const float gx = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src * 4u), __float_as_int(hx)));
         const float gy = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src * 4u), __float_as_int(hy)));
@@ -129,7 +129,7 @@ __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixe
         if (got) {
             x = gx; y = gy; z = gz;
         }
-        nm = wave_ballot(need);
+        nm &= ~wave_ballot(got);
     }
 }
 
@@ -265,9 +265,10 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
     float w_closest = INFINITY;
     bool w_pending = false;
 
+    unsigned long long idle_lanes = ~0ull; // the lanes without a path (= !active), kept as a lane mask too
     for (;;) {
         // ---- refill idle lanes from the wave's chunk, pulling new chunks as needed
-        unsigned long long need = wave_ballot(!active);
+        unsigned long long need = idle_lanes;
         while (need != 0ull && !queue_empty) {
             if (w_next >= w_end) {
                 const ConstArgs kq = fresh_args(); // the call's shape is needed once per chunk: not worth registers
@@ -336,7 +337,10 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             const int ch_x0 = s_x0[cur], ch_y0 = s_y0[cur], ch_tw = s_tw[cur], ch_npx = s_npx[cur];
             const uint32_t avail = w_end - w_next;
             const uint32_t rank = lane_rank(need);
-            const bool got = ((need >> lane) & 1ull) && rank < avail;
+            // the idle lanes that get an item, as a lane mask first (a vote on a register comparison),
+            // then as this lane's flag
+            const unsigned long long got_lanes = need & wave_ballot(rank < avail);
+            const bool got = __builtin_amdgcn_inverse_ballot_w64(got_lanes);
             if (got) {
                 RT_TALLY(wc, kSecRefill);
                 // Item w_next + rank is j = w_pix + rank pixels on from sample w_smp's first.  j / pixels
@@ -377,12 +381,15 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             const uint32_t whole = (uint32_t)(((float)w_pix + 0.5f) * w_inv_npx);
             w_smp += whole;
             w_pix -= __umul24(whole, (uint32_t)ch_npx);
-            need &= ~wave_ballot(got);
+            need &= ~got_lanes;
         }
 
         RT_CLOCK(wc, kTimeRefill, t_mark);
         // ---- termination
-        const bool wave_active = wave_any(active);
+        // `need` has a bit for every lane that is still idle (all 64 lanes of a wave exist here)
+        const unsigned long long active_lanes = ~need;
+        idle_lanes = need;
+        const bool wave_active = active_lanes != 0ull;
         if (MULTI_TILE) {
             if (lane == 0)
                 wave_flags[wave] = wave_active ? 1u : 0u;
@@ -418,12 +425,12 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
                 }
             }
             if (wave_active) {
+                // (a lane without a path, or whose ray has finished its walk or takes none, holds kBvhDone)
                 uint32_t *stk = reinterpret_cast<uint32_t *>(stage) + tid;
-                const bool walking = active && w_node != kBvhDone;
                 if (bvh.lds_nodes)
-                    bvh_walk<true>(bvh, bvh_lds, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best, wc);
+                    bvh_walk<true>(bvh, bvh_lds, ray, stk, 0.001f, w_node, w_sp, w_closest, w_best, wc);
                 else
-                    bvh_walk<false>(bvh, nullptr, ray, stk, walking, 0.001f, w_node, w_sp, w_closest, w_best, wc);
+                    bvh_walk<false>(bvh, nullptr, ray, stk, 0.001f, w_node, w_sp, w_closest, w_best, wc);
             }
             if (active && w_node == kBvhDone) {
                 w_pending = false;
@@ -624,8 +631,9 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
         RT_CLOCK(wc, kTimeShade, t_mark);
         // ---- chunks whose last path has just terminated: add their sums to the frame
         const unsigned long long term = wave_ballot(terminated);
+        idle_lanes |= term;
         if (term != 0ull) {
-            const unsigned long long term1 = wave_ballot(terminated && acc_at >= 192u);
+            const unsigned long long term1 = term & wave_ballot(acc_at >= 192u);
             s_done1 += (uint32_t)__popcll(term1);
             s_done0 += (uint32_t)__popcll(term & ~term1);
 #pragma unroll
