@@ -148,9 +148,11 @@ __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, f
 
 // Must be called by all 64 lanes.  The lanes whose node is not kBvhDone walk (they hold a tame ray
 // and the state bvh_begin or an earlier call left); every other lane must hold kBvhDone.
-template <bool NODES_IN_LDS>
+// Stack entries are child references: four bytes, or two (sign-extended when read) for a tree in LDS,
+// whose host side makes sure that every reference fits (kBvhLdsRecords).
+template <bool NODES_IN_LDS, typename StackEntry>
 __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nodes, const RayState &r,
-                                         uint32_t *stk, float tmin, int &node, uint32_t &sp,
+                                         StackEntry *stk, float tmin, int &node, uint32_t &sp,
                                          float &closest, int &best, WorkCount *wc = nullptr)
 {
     const uint32_t n_start = (uint32_t)__popcll(wave_ballot(node != kBvhDone));
@@ -215,7 +217,7 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
             const int c0 = __float_as_int(l0.w), c1 = __float_as_int(h0.w);
             if (hit0 && hit1) {
                 const bool first0 = n0 <= n1;
-                stk[sp * kTraceThreads] = (uint32_t)(first0 ? c1 : c0);
+                stk[sp * kTraceThreads] = (StackEntry)(first0 ? c1 : c0);
                 ++sp;
                 node = first0 ? c0 : c1;
             } else if (hit0) {

@@ -316,7 +316,8 @@ int bvh_args(rt_context *ctx, BvhArgs &out, bool may_build = true)
     out.n_nodes = (uint32_t)b.nodes.size();
     out.n_large = b.n_large;
     out.levels = b.levels ? b.levels : 1u;
-    out.lds_nodes = out.n_nodes <= ctx->bvh_lds_nodes_max ? out.n_nodes : 0u;
+    out.lds_nodes = (out.n_nodes <= ctx->bvh_lds_nodes_max && out.n_nodes < 32768u && b.leaf_geom.size() <= kBvhLdsRecords)
+                        ? out.n_nodes : 0u;
     out.suspend_lanes = ctx->bvh_suspend_lanes;
     memcpy(out.center, b.center, sizeof out.center);
     out.radius2 = std::nextafter(b.radius * b.radius, INFINITY);

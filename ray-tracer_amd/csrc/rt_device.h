@@ -43,6 +43,10 @@ enum {
     kFilterBvh = 3           // per-ray walk of a box hierarchy; the spheres in the leaves reached are candidates
 };
 
+// A tree is walked in LDS only if its records number at most this many: the walk's stack then holds
+// child references in two bytes, and a leaf reference ~(first << 4 | count) must fit 16 signed bits.
+constexpr uint32_t kBvhLdsRecords = 2048;
+
 // Device view of the hierarchy (see rt_bvh.h for the encoding).
 struct BvhArgs {
     const float4 *nodes;        // four float4 per node

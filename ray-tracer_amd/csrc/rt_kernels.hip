@@ -60,12 +60,12 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long m);
 // one Philox block per attempt, with the lanes helping
 // each other.  A lane's attempts are the Philox blocks call, call + 1, ... of its own (pixel,
 // sample) stream, and it must take the FIRST one inside the sphere; which lane evaluates an
-// attempt does not matter.  Every lane tries its attempt 0 itself (52 % succeed).  The rest publish
-// their stream in LDS, and in each further round all 64 lanes evaluate `per` consecutive attempts
+// attempt does not matter.  Every lane tries its attempt 0 itself (52 % succeed).  The rest say
+// in LDS which lanes they are, and in each further round all 64 lanes evaluate `per` consecutive attempts
 // for each of them (per = the power of two that fits, at most 16); a lane takes its first success
 // and advances its counter past it, or past all `per` attempts if none succeeded.  Two rounds
 // usually do where the plain loop makes the wave wait for its unluckiest lane (five or six
-// attempts).  Must be called by all 64 lanes; `coop` = 192 words of LDS owned by the wave.
+// attempts).  Must be called by all 64 lanes; `coop` = 64 words of LDS owned by the wave.
 __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixel, uint32_t sample, uint32_t &call,
                                                         uint32_t k0, uint32_t k1, uint32_t *coop, int lane,
                                                         float &x, float &y, float &z, WorkCount *wc = nullptr)
@@ -93,18 +93,21 @@ __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixe
         lg = lg > 4u ? 4u : lg;
         const uint32_t per = 1u << lg;
         const uint32_t k = lane_rank(nm);
-        if (need) {
-            coop[k] = pixel;
-            coop[64u + k] = sample;
-            coop[128u + k] = call;
-        }
+        // the k-th lane still looking says which lane it is; its helpers read its stream's
+        // coordinates out of its registers
+        if (need)
+            coop[k] = (uint32_t)lane * 4u;
         __builtin_amdgcn_wave_barrier();
         const uint32_t t = (uint32_t)lane >> lg, at = (uint32_t)lane & (per - 1u);
+        const int from = (int)coop[t < n ? t : 0u];
+        const uint32_t h_pixel = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pixel);
+        const uint32_t h_sample = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)sample);
+        const uint32_t h_call = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)call);
         float hx = 0.0f, hy = 0.0f, hz = 0.0f, hlen2 = 2.0f;
         if (t < n) {
             uint32_t w[4];
             RT_TALLY(wc, kSecPointHelp);
-            philox4x32_10(coop[t], coop[64u + t], coop[128u + t] + at, k0, k1, w);
+            philox4x32_10(h_pixel, h_sample, h_call + at, k0, k1, w);
             hx = range_m1_p1(w[0]);
             hy = range_m1_p1(w[1]);
             hz = range_m1_p1(w[2]);
@@ -187,7 +190,8 @@ __device__ __forceinline__ BvhArgs fresh_bvh_args()
 enum { kPlain = 0, kExt = 1, kCount = 2 };
 
 template <bool MULTI_TILE, int FILTER, int VARIANT>
-__global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) trace_kernel(const TraceArgs a)
+__global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? (VARIANT == kPlain ? 6 : 5) : 4)
+trace_kernel(const TraceArgs a)
 {
     constexpr bool EXT = VARIANT == kExt;
     WorkCount work = {};
@@ -216,12 +220,14 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
         load_tile(tile_f, tile_e, filt_src, a.exact, 0u, n_pad);
         __syncthreads();
     }
-    // hierarchy scan: the nodes of a small tree live in LDS, behind the walk's stack
-    float4 *bvh_lds = reinterpret_cast<float4 *>(stage) + (size_t)a.bvh.levels * (kTraceThreads / 4);
-    // 192 words per wave for unit_sphere_points_wave: the head of the wave's own operand staging
+    // hierarchy scan: the nodes of a small tree live in LDS, behind the walk's stack (whose entries
+    // are two bytes then, four for a tree walked in memory)
+    float4 *bvh_lds = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(stage) +
+                                                 (size_t)a.bvh.levels * kTraceThreads * (a.bvh.lds_nodes ? 2u : 4u));
+    // 64 words per wave for unit_sphere_points_wave: the head of the wave's own operand staging
     // slice in the list scans (idle while paths are shaded), or a region behind the hierarchy's nodes
     uint32_t *coop = FILTER == kFilterBvh
-                         ? reinterpret_cast<uint32_t *>(bvh_lds + (size_t)a.bvh.lds_nodes * 4u) + (threadIdx.x >> 6) * 192
+                         ? reinterpret_cast<uint32_t *>(bvh_lds + (size_t)a.bvh.lds_nodes * 4u) + (threadIdx.x >> 6) * 64
                          : reinterpret_cast<uint32_t *>(stage) + (threadIdx.x >> 6) * (9 * 64);
     if (FILTER == kFilterBvh && a.bvh.lds_nodes) {
         for (uint32_t i = threadIdx.x; i < a.bvh.lds_nodes * 4u; i += blockDim.x)
@@ -426,11 +432,12 @@ __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? 5 : 4) t
             }
             if (wave_active) {
                 // (a lane without a path, or whose ray has finished its walk or takes none, holds kBvhDone)
-                uint32_t *stk = reinterpret_cast<uint32_t *>(stage) + tid;
                 if (bvh.lds_nodes)
-                    bvh_walk<true>(bvh, bvh_lds, ray, stk, 0.001f, w_node, w_sp, w_closest, w_best, wc);
+                    bvh_walk<true>(bvh, bvh_lds, ray, reinterpret_cast<int16_t *>(stage) + tid, 0.001f, w_node, w_sp,
+                                   w_closest, w_best, wc);
                 else
-                    bvh_walk<false>(bvh, nullptr, ray, stk, 0.001f, w_node, w_sp, w_closest, w_best, wc);
+                    bvh_walk<false>(bvh, nullptr, ray, reinterpret_cast<uint32_t *>(stage) + tid, 0.001f, w_node, w_sp,
+                                    w_closest, w_best, wc);
             }
             if (active && w_node == kBvhDone) {
                 w_pending = false;
@@ -911,8 +918,8 @@ hipError_t static_scratch_address(void **ptr)
 uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels, uint32_t bvh_lds_nodes)
 {
     if (filter == kFilterBvh)
-        return (bvh_levels ? bvh_levels : 1u) * kTraceThreads * (uint32_t)sizeof(uint32_t) + bvh_lds_nodes * 64u +
-               4u * 192u * (uint32_t)sizeof(uint32_t);
+        return (bvh_levels ? bvh_levels : 1u) * kTraceThreads * (bvh_lds_nodes ? 2u : 4u) + bvh_lds_nodes * 64u +
+               4u * 64u * (uint32_t)sizeof(uint32_t);
     return 4u * 9u * 64u * (uint32_t)sizeof(float);
 }
 
