@@ -42,7 +42,7 @@ for n, grid, spp in ((500, 11, 64), (10000, 50, 64)):
     for chunks in (4, 8, 16, 32, 64):
         ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, chunks)
         print(f"  chunks per wave {chunks}: {frame_ms(p):.3f} ms", flush=True)
-    ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, 16)
+    ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, 32)
     for nodes in (0, 512, 1024, 2048):
         ctx.set_option(rtamd.OPT_BVH_LDS_NODES, nodes)
         print(f"  nodes in LDS up to {nodes}: {frame_ms(p):.3f} ms", flush=True)
