@@ -190,7 +190,7 @@ __device__ __forceinline__ BvhArgs fresh_bvh_args()
 enum { kPlain = 0, kExt = 1, kCount = 2 };
 
 template <bool MULTI_TILE, int FILTER, int VARIANT>
-__global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? (VARIANT == kPlain ? 6 : 5) : 4)
+__global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? (VARIANT == kCount ? 5 : 6) : 4)
 trace_kernel(const TraceArgs a)
 {
     constexpr bool EXT = VARIANT == kExt;
