@@ -228,7 +228,7 @@ trace_kernel(const TraceArgs a)
     // slice in the list scans (idle while paths are shaded), or a region behind the hierarchy's nodes
     uint32_t *coop = FILTER == kFilterBvh
                          ? reinterpret_cast<uint32_t *>(bvh_lds + (size_t)a.bvh.lds_nodes * 4u) + (threadIdx.x >> 6) * 64
-                         : reinterpret_cast<uint32_t *>(stage) + (threadIdx.x >> 6) * (9 * 64);
+                         : reinterpret_cast<uint32_t *>(stage) + (threadIdx.x >> 6) * (FILTER == kFilterMatrix ? 9 * 64 : 64);
     if (FILTER == kFilterBvh && a.bvh.lds_nodes) {
         for (uint32_t i = threadIdx.x; i < a.bvh.lds_nodes * 4u; i += blockDim.x)
             bvh_lds[i] = a.bvh.nodes[i];
@@ -920,7 +920,8 @@ uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels, uint32_t bvh_lds_nodes
     if (filter == kFilterBvh)
         return (bvh_levels ? bvh_levels : 1u) * kTraceThreads * (bvh_lds_nodes ? 2u : 4u) + bvh_lds_nodes * 64u +
                4u * 64u * (uint32_t)sizeof(uint32_t);
-    return 4u * 9u * 64u * (uint32_t)sizeof(float);
+    // matrix scan: 4 waves x 9 x 64 floats of operand staging; the other list scans: the point helper's 64 words per wave
+    return 4u * (filter == kFilterMatrix ? 9u * 64u : 64u) * (uint32_t)sizeof(float);
 }
 
 size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth, uint32_t stack_entry_bytes)
