@@ -289,7 +289,8 @@ typedef enum rt_option {
     RT_OPT_WORKGROUPS_PER_CU = 2, /* cap on resident workgroups per CU, 0 = occupancy limit */
     RT_OPT_BVH_LEAF_SPHERES = 3,  /* most spheres per leaf of the hierarchy, 1..15 (default: 4, or 8 for trees too large for LDS) */
     RT_OPT_BVH_MIN_SPHERES = 4,   /* scene size from which the automatic choice is the hierarchy */
-    RT_OPT_BVH_LDS_NODES = 5,     /* hierarchies of up to this many nodes are walked in LDS, 0..2048 (default 512) */
+    RT_OPT_BVH_LDS_NODES = 5,     /* hierarchies of up to this many nodes (and at most 2048 sphere records) are walked
+                                     in LDS, 0..2048 (default 512) */
     RT_OPT_BVH_SUSPEND_LANES = 6, /* a 64-lane wave stops walking the hierarchy when at most this many of its rays
                                      are still at it; they resume in the wave's next pass (0..63, 0 = never) */
     RT_OPT_CHUNKS_PER_WAVE = 7,   /* work queue granularity: a call whose 8x8-pixel tiles number fewer than this many
