@@ -52,6 +52,21 @@ def test_ten_thousand_spheres(ctx):
     same_as_oracle(ctx, sc, ((0.0, 30.0, 0.0), (5.0, 0.0, 5.0), (0.0, 0.0, 1.0), 60.0), 64, 36, 2, 8, 5)  # from above
 
 
+@pytest.mark.parametrize("n", [2040, 2047, 2048, 2049, 2052])
+def test_trees_at_the_limit_of_two_byte_stack_entries(ctx, n):
+    """Trees whose nodes fit the LDS copy are walked with child references in two bytes, which holds
+    a leaf reference only up to record 2047: with leaves of 15 a 2 040-sphere scene has few enough
+    nodes for LDS and records right up to that limit; a few spheres more and the tree must be walked
+    from memory with four-byte entries.  Both sides of the limit against the oracle."""
+    ctx.set_option(rtamd.OPT_BVH_LEAF_SPHERES, 15)
+    try:
+        st, nodes, levels, large, records = rtamd.accel_selfcheck(scenes.random_spheres(n, grid_half=24, seed=3), 15)
+        assert st == 0 and nodes <= 512 and records == n
+        same_as_oracle(ctx, scenes.random_spheres(n, grid_half=24, seed=3), C3_CAM, 96, 54, 2, 8, 11)
+    finally:
+        ctx.set_option(rtamd.OPT_BVH_LEAF_SPHERES, 4)
+
+
 def test_hundred_thousand_spheres_walked_from_memory(ctx):
     """A tree far too large for LDS (33 000 nodes, 17 levels): nodes and leaf records come through
     the caches, and bounce stack entries take four bytes (n > 65536)."""
