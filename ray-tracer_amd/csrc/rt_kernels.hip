@@ -189,11 +189,15 @@ __device__ __forceinline__ BvhArgs fresh_bvh_args()
 // (RT_OPT_COUNT_WORK; slower, same results).
 enum { kPlain = 0, kExt = 1, kCount = 2 };
 
-template <bool MULTI_TILE, int FILTER, int VARIANT>
+// SPLIT: for the list scans, the list does not fit one LDS tile and is scanned tile by tile; for the
+// hierarchy scan (which has no tiles), the nodes are read from memory instead of from an LDS copy.
+template <bool SPLIT, int FILTER, int VARIANT>
 __global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? (VARIANT == kCount ? 5 : 6) : 4)
 trace_kernel(const TraceArgs a)
 {
     constexpr bool EXT = VARIANT == kExt;
+    constexpr bool MULTI_TILE = SPLIT && FILTER != kFilterBvh;
+    constexpr bool NODES_IN_LDS = !SPLIT && FILTER == kFilterBvh;
     WorkCount work = {};
     WorkCount *const wc = VARIANT == kCount ? &work : nullptr;
     const unsigned long long t_start = VARIANT == kCount ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -432,7 +436,7 @@ trace_kernel(const TraceArgs a)
             }
             if (wave_active) {
                 // (a lane without a path, or whose ray has finished its walk or takes none, holds kBvhDone)
-                if (bvh.lds_nodes)
+                if (NODES_IN_LDS)
                     bvh_walk<true>(bvh, bvh_lds, ray, reinterpret_cast<int16_t *>(stage) + tid, 0.001f, w_node, w_sp,
                                    w_closest, w_best, wc);
                 else
@@ -936,7 +940,8 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
 {
     (void)hipGetLastError(); // a failure of some earlier, unrelated runtime call is not this launch\'s
     const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
-    const bool multi = a.filter != kFilterBvh && a.n > a.tile_cap;
+    // the kernels' SPLIT: a list in several tiles, or a hierarchy whose nodes stay in memory
+    const bool multi = a.filter == kFilterBvh ? a.bvh.lds_nodes == 0u : a.n > a.tile_cap;
     const dim3 grid(n_workgroups), block(kTraceThreads);
     const bool glass = (a.flags & (RT_FLAG_DIELECTRIC | RT_FLAG_FLOAT_SHADING)) != 0u; // the extended kernels
     const bool count = a.count_work != 0u && !glass; // tallies exist for the reference's behaviour only
@@ -959,14 +964,7 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
     case kFilterExact: RT_LAUNCH_TRACE(kFilterExact); break;
     case kFilterConservative: RT_LAUNCH_TRACE(kFilterConservative); break;
     case kFilterMatrix: RT_LAUNCH_TRACE(kFilterMatrix); break;
-    case kFilterBvh:
-        if (glass)
-            hipLaunchKernelGGL((trace_kernel<false, kFilterBvh, kExt>), grid, block, lds, stream, a);
-        else if (count)
-            hipLaunchKernelGGL((trace_kernel<false, kFilterBvh, kCount>), grid, block, lds, stream, a);
-        else
-            hipLaunchKernelGGL((trace_kernel<false, kFilterBvh, kPlain>), grid, block, lds, stream, a);
-        break;
+    case kFilterBvh: RT_LAUNCH_TRACE(kFilterBvh); break;
     default:
         return hipErrorInvalidValue;
     }
