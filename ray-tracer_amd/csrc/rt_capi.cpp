@@ -432,21 +432,28 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
             a.subtiles = 4u;
         per_tile = (per_tile + a.subtiles - 1u) / a.subtiles;
         const uint32_t min_segment = 4u * a.subtiles; // 256 paths on 64, 32 or 16 pixels
+        uint32_t per = a.sample_count;
         if (per_tile >= 2u && a.sample_count >= 2u * min_segment) {
-            uint32_t per = (uint32_t)((a.sample_count + per_tile - 1u) / per_tile);
+            per = (uint32_t)((a.sample_count + per_tile - 1u) / per_tile);
             if (per < min_segment)
                 per = min_segment;
+        }
+        // a wave sums a chunk's samples of a pixel in 16 bits per channel: at most 257 samples of 255
+        if (per > kSegmentSamplesMax)
+            per = kSegmentSamplesMax;
+        if (per < a.sample_count) {
             a.segments = (a.sample_count + per - 1u) / per; // every segment non-empty
             a.seg_samples = per;
         }
-        const uint64_t total = (uint64_t)a.n_chunks * a.subtiles * a.segments;
-        if (total > 0x7fffffffull) {
+        uint64_t total = (uint64_t)a.n_chunks * a.subtiles * a.segments;
+        if (total > 0x7fffffffull && a.subtiles > 1u) {
             a.subtiles = 1u;
-            a.segments = 1u;
-            a.seg_samples = a.sample_count;
-        } else {
-            a.n_chunks = (uint32_t)total;
+            total = (uint64_t)a.n_chunks * a.segments;
         }
+        if (total > 0x7fffffffull)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT,
+                        "too many tiles x samples for one call's work queue: split the samples over several calls");
+        a.n_chunks = (uint32_t)total;
     }
     a.direct_add = a.seg_samples <= ctx->direct_add_samples ? 1u : 0u;
     const uint32_t by_chunks = (a.n_chunks + 3u) / 4u;

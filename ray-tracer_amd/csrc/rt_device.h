@@ -43,6 +43,10 @@ enum {
     kFilterBvh = 3           // per-ray walk of a box hierarchy; the spheres in the leaves reached are candidates
 };
 
+// Most samples of a pixel in one work-queue chunk: a wave keeps a chunk's per-pixel sums in 16 bits per
+// channel, and a sample adds at most 255.
+constexpr uint32_t kSegmentSamplesMax = 256;
+
 // A tree is walked in LDS only if its records number at most this many: the walk's stack then holds
 // child references in two bytes, and a leaf reference ~(first << 4 | count) must fit 16 signed bits.
 constexpr uint32_t kBvhLdsRecords = 2048;

@@ -65,9 +65,9 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long m);
 // for each of them (per = the power of two that fits, at most 16); a lane takes its first success
 // and advances its counter past it, or past all `per` attempts if none succeeded.  Two rounds
 // usually do where the plain loop makes the wave wait for its unluckiest lane (five or six
-// attempts).  Must be called by all 64 lanes; `coop` = 64 words of LDS owned by the wave.
+// attempts).  Must be called by all 64 lanes; `coop` = 64 bytes of LDS owned by the wave.
 __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixel, uint32_t sample, uint32_t &call,
-                                                        uint32_t k0, uint32_t k1, uint32_t *coop, int lane,
+                                                        uint32_t k0, uint32_t k1, uint8_t *coop, int lane,
                                                         float &x, float &y, float &z, WorkCount *wc = nullptr)
 {
     // Wave votes are taken on comparisons of register values, and the set of lanes still looking
@@ -96,10 +96,10 @@ __device__ __forceinline__ void unit_sphere_points_wave(bool want, uint32_t pixe
         // the k-th lane still looking says which lane it is; its helpers read its stream's
         // coordinates out of its registers
         if (need)
-            coop[k] = (uint32_t)lane * 4u;
+            coop[k] = (uint8_t)lane;
         __builtin_amdgcn_wave_barrier();
         const uint32_t t = (uint32_t)lane >> lg, at = (uint32_t)lane & (per - 1u);
-        const int from = (int)coop[t < n ? t : 0u];
+        const int from = (int)coop[t < n ? t : 0u] * 4;
         const uint32_t h_pixel = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pixel);
         const uint32_t h_sample = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)sample);
         const uint32_t h_call = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)call);
@@ -192,7 +192,7 @@ enum { kPlain = 0, kExt = 1, kCount = 2 };
 // SPLIT: for the list scans, the list does not fit one LDS tile and is scanned tile by tile; for the
 // hierarchy scan (which has no tiles), the nodes are read from memory instead of from an LDS copy.
 template <bool SPLIT, int FILTER, int VARIANT>
-__global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? (VARIANT == kCount ? 5 : 6) : 4)
+__global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? (VARIANT == kCount ? 5 : 7) : 4)
 trace_kernel(const TraceArgs a)
 {
     constexpr bool EXT = VARIANT == kExt;
@@ -212,7 +212,9 @@ trace_kernel(const TraceArgs a)
     const int stack_levels = a.max_depth > 0 ? a.max_depth : 1;
     uint32_t *wave_flags = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(stack) +
                                                         (size_t)stack_levels * kTraceThreads * a.stack_entry_bytes);
-    uint32_t *acc_base = wave_flags + 4; // 4 waves x 2 chunk slots x 64 pixels x 3 channels
+    // 4 waves x 2 chunk slots x 64 pixels x 2 words: a pixel's red and green sums in the halves of one
+    // word, its blue sum in the next (a chunk adds at most 256 samples of at most 255 to a pixel)
+    uint32_t *acc_base = wave_flags + 4;
     const Geom *filt_src = FILTER == kFilterExact ? nullptr : a.geom;
 
     const int tid = threadIdx.x;
@@ -228,11 +230,11 @@ trace_kernel(const TraceArgs a)
     // are two bytes then, four for a tree walked in memory)
     float4 *bvh_lds = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(stage) +
                                                  (size_t)a.bvh.levels * kTraceThreads * (a.bvh.lds_nodes ? 2u : 4u));
-    // 64 words per wave for unit_sphere_points_wave: the head of the wave's own operand staging
-    // slice in the list scans (idle while paths are shaded), or a region behind the hierarchy's nodes
-    uint32_t *coop = FILTER == kFilterBvh
-                         ? reinterpret_cast<uint32_t *>(bvh_lds + (size_t)a.bvh.lds_nodes * 4u) + (threadIdx.x >> 6) * 64
-                         : reinterpret_cast<uint32_t *>(stage) + (threadIdx.x >> 6) * (FILTER == kFilterMatrix ? 9 * 64 : 64);
+    // 64 bytes per wave for unit_sphere_points_wave: the head of the wave's own operand staging
+    // slice in the matrix scan (idle while paths are shaded), else a region of its own
+    uint8_t *coop = FILTER == kFilterBvh
+                        ? reinterpret_cast<uint8_t *>(bvh_lds + (size_t)a.bvh.lds_nodes * 4u) + (threadIdx.x >> 6) * 64
+                        : reinterpret_cast<uint8_t *>(stage) + (threadIdx.x >> 6) * (FILTER == kFilterMatrix ? 9 * 64 * 4 : 64);
     if (FILTER == kFilterBvh && a.bvh.lds_nodes) {
         for (uint32_t i = threadIdx.x; i < a.bvh.lds_nodes * 4u; i += blockDim.x)
             bvh_lds[i] = a.bvh.nodes[i];
@@ -243,8 +245,8 @@ trace_kernel(const TraceArgs a)
     // are added to the frame once, when the chunk's last path has terminated: with plain loads
     // and stores while a tile's samples are one chunk (its 64 pixels then belong to this wave
     // alone during the launch), with atomics when the samples are split over several chunks.
-    uint32_t *acc = acc_base + wave * (2 * 64 * 3);
-    for (int i = lane; i < 2 * 64 * 3; i += 64)
+    uint32_t *acc = acc_base + wave * (2 * 64 * 2);
+    for (int i = lane; i < 2 * 64 * 2; i += 64)
         acc[i] = 0u;
 
     // wave-uniform queue state; slot s is free while s_total[s] == 0
@@ -265,7 +267,7 @@ trace_kernel(const TraceArgs a)
     bool active = false;
     RayState ray = {};
     uint32_t pixel = 0u, sample = 0u, call = 0u;
-    uint32_t acc_at = 0u; // index of this path's pixel in acc: slot * 192 + pixel-in-chunk * 3
+    uint32_t acc_at = 0u; // index of this path's pixel in acc: slot * 128 + pixel-in-chunk * 2
     int depth = 0, level = 0;
     uint32_t n_rays = 0u;
     uint32_t n_rounds = 0u; // wave-uniform: passes over the sphere list
@@ -365,7 +367,7 @@ trace_kernel(const TraceArgs a)
                 const int px = ch_x0 + lx, py = ch_y0 + ly;
                 pixel = (uint32_t)px + (uint32_t)py * a.width;
                 sample = s_smp[cur] + w_smp + s;
-                acc_at = (uint32_t)cur * 192u + p * 3u;
+                acc_at = (uint32_t)cur * 128u + p * 2u;
                 call = 0u;
                 uint32_t w[4];
                 philox4x32_10(pixel, sample, call++, a.key0, a.key1, w);
@@ -604,9 +606,8 @@ trace_kernel(const TraceArgs a)
                     atomicAdd(dst + 1, (uint32_t)to_byte(fg));
                     atomicAdd(dst + 2, (uint32_t)to_byte(fb));
                 } else {
-                    atomicAdd(acc + acc_at + 0u, (uint32_t)to_byte(fr));
-                    atomicAdd(acc + acc_at + 1u, (uint32_t)to_byte(fg));
-                    atomicAdd(acc + acc_at + 2u, (uint32_t)to_byte(fb));
+                    atomicAdd(acc + acc_at + 0u, (uint32_t)to_byte(fr) | ((uint32_t)to_byte(fg) << 16));
+                    atomicAdd(acc + acc_at + 1u, (uint32_t)to_byte(fb));
                 }
                 active = false;
             } else if (terminated) {
@@ -631,9 +632,8 @@ trace_kernel(const TraceArgs a)
                     atomicAdd(dst + 1, (uint32_t)cg);
                     atomicAdd(dst + 2, (uint32_t)cb);
                 } else {
-                    atomicAdd(acc + acc_at + 0u, (uint32_t)cr);
-                    atomicAdd(acc + acc_at + 1u, (uint32_t)cg);
-                    atomicAdd(acc + acc_at + 2u, (uint32_t)cb);
+                    atomicAdd(acc + acc_at + 0u, (uint32_t)cr | ((uint32_t)cg << 16));
+                    atomicAdd(acc + acc_at + 1u, (uint32_t)cb);
                 }
                 active = false;
             }
@@ -644,7 +644,7 @@ trace_kernel(const TraceArgs a)
         const unsigned long long term = wave_ballot(terminated);
         idle_lanes |= term;
         if (term != 0ull) {
-            const unsigned long long term1 = term & wave_ballot(acc_at >= 192u);
+            const unsigned long long term1 = term & wave_ballot(acc_at >= 128u);
             s_done1 += (uint32_t)__popcll(term1);
             s_done0 += (uint32_t)__popcll(term & ~term1);
 #pragma unroll
@@ -655,14 +655,15 @@ trace_kernel(const TraceArgs a)
                         const ConstArgs ka = fresh_args();
                         const int ly = lane / s_tw[sl], lx = lane - ly * s_tw[sl];
                         uint32_t *dst = ka->sums + ((size_t)(s_x0[sl] + lx) + (size_t)(s_y0[sl] + ly) * ka->width) * 3u;
-                        uint32_t *src = acc + sl * 192 + lane * 3;
+                        uint32_t *src = acc + sl * 128 + lane * 2;
+                        const uint32_t sum[3] = { src[0] & 0xffffu, src[0] >> 16, src[1] };
+                        src[0] = src[1] = 0u;
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch) {
                             if (a.segments > 1u)
-                                atomicAdd(dst + ch, src[ch]);
+                                atomicAdd(dst + ch, sum[ch]);
                             else
-                                dst[ch] += src[ch];
-                            src[ch] = 0u;
+                                dst[ch] += sum[ch];
                         }
                     }
                     if (sl) s_total1 = 0u; else s_total0 = 0u;
@@ -922,10 +923,9 @@ hipError_t static_scratch_address(void **ptr)
 uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels, uint32_t bvh_lds_nodes)
 {
     if (filter == kFilterBvh)
-        return (bvh_levels ? bvh_levels : 1u) * kTraceThreads * (bvh_lds_nodes ? 2u : 4u) + bvh_lds_nodes * 64u +
-               4u * 64u * (uint32_t)sizeof(uint32_t);
-    // matrix scan: 4 waves x 9 x 64 floats of operand staging; the other list scans: the point helper's 64 words per wave
-    return 4u * (filter == kFilterMatrix ? 9u * 64u : 64u) * (uint32_t)sizeof(float);
+        return (bvh_levels ? bvh_levels : 1u) * kTraceThreads * (bvh_lds_nodes ? 2u : 4u) + bvh_lds_nodes * 64u + 4u * 64u;
+    // matrix scan: 4 waves x 9 x 64 floats of operand staging; the other list scans: the point helper's 64 bytes per wave
+    return filter == kFilterMatrix ? 4u * 9u * 64u * (uint32_t)sizeof(float) : 4u * 64u;
 }
 
 size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth, uint32_t stack_entry_bytes)
@@ -933,7 +933,7 @@ size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth,
     const size_t levels = max_depth > 0 ? (size_t)max_depth : 1u;
     return (size_t)tile_cap * 2u * sizeof(Geom) + aux_bytes +
            levels * kTraceThreads * stack_entry_bytes + 4u * sizeof(uint32_t) +
-           4u * 2u * 64u * 3u * sizeof(uint32_t);
+           4u * 2u * 64u * 2u * sizeof(uint32_t);
 }
 
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream)
