@@ -198,6 +198,8 @@ trace_kernel(const TraceArgs a)
     constexpr bool EXT = VARIANT == kExt;
     constexpr bool MULTI_TILE = SPLIT && FILTER != kFilterBvh;
     constexpr bool NODES_IN_LDS = !SPLIT && FILTER == kFilterBvh;
+    // a tree in LDS has at most 2048 records: its bounce stack entries take two bytes, known here
+    const uint32_t bounce_bytes = NODES_IN_LDS ? 2u : a.stack_entry_bytes;
     WorkCount work = {};
     WorkCount *const wc = VARIANT == kCount ? &work : nullptr;
     const unsigned long long t_start = VARIANT == kCount ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -211,7 +213,7 @@ trace_kernel(const TraceArgs a)
     uint32_t *stack = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(stage) + a.aux_bytes);
     const int stack_levels = a.max_depth > 0 ? a.max_depth : 1;
     uint32_t *wave_flags = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(stack) +
-                                                        (size_t)stack_levels * kTraceThreads * a.stack_entry_bytes);
+                                                        (size_t)stack_levels * kTraceThreads * bounce_bytes);
     // 4 waves x 2 chunk slots x 64 pixels x 2 words: a pixel's red and green sums in the halves of one
     // word, its blue sum in the next (a chunk adds at most 256 samples of at most 255 to a pixel)
     uint32_t *acc_base = wave_flags + 4;
@@ -545,7 +547,7 @@ trace_kernel(const TraceArgs a)
                         ndy = (ratio * uy - f * ny) * keep;
                         ndz = (ratio * uz - f * nz) * keep;
                     }
-                    push_bounce(stack, a.stack_entry_bytes, level * kTraceThreads + tid, (uint32_t)best);
+                    push_bounce(stack, bounce_bytes, level * kTraceThreads + tid, (uint32_t)best);
                     ++level;
                     --depth;
                     ray.ox = px; ray.oy = py; ray.oz = pz;
@@ -572,7 +574,7 @@ trace_kernel(const TraceArgs a)
                         ndz = ray.dz - (nz * d) * 2.0f;
                         ndx = ndx + (fuzz * rx); ndy = ndy + (fuzz * ry); ndz = ndz + (fuzz * rz);
                     }
-                    push_bounce(stack, a.stack_entry_bytes, level * kTraceThreads + tid, (uint32_t)best);
+                    push_bounce(stack, bounce_bytes, level * kTraceThreads + tid, (uint32_t)best);
                     ++level;
                     --depth;
                     ray.ox = px; ray.oy = py; ray.oz = pz;
@@ -591,7 +593,7 @@ trace_kernel(const TraceArgs a)
                 // EXTENSION (RT_FLAG_FLOAT_SHADING): the same replay with the colour kept in float,
                 // limited to [0, 255] per level, truncated to bytes once per sample
                 for (int l = level - 1; l >= 0; --l) {
-                    const rt_sphere *sp = a.spheres + read_bounce(stack, a.stack_entry_bytes, l * kTraceThreads + tid);
+                    const rt_sphere *sp = a.spheres + read_bounce(stack, bounce_bytes, l * kTraceThreads + tid);
                     if (sp->material == RT_MAT_DIFFUSE) {
                         fr = fr * 0.5f; fg = fg * 0.5f; fb = fb * 0.5f;
                     }
@@ -615,7 +617,7 @@ trace_kernel(const TraceArgs a)
                 // stays black at every level (ToRGB of Color * 0, or of NaN for a non-finite Color, is 0),
                 // so the paths that ran out of depth -- the longest stacks -- have nothing to unwind.
                 for (int l = (cr | cg | cb) != 0 ? level - 1 : -1; l >= 0; --l) {
-                    const rt_sphere *sp = a.spheres + read_bounce(stack, a.stack_entry_bytes, l * kTraceThreads + tid);
+                    const rt_sphere *sp = a.spheres + read_bounce(stack, bounce_bytes, l * kTraceThreads + tid);
                     RT_TALLY(wc, kSecReplayLevel);
                     if (sp->material == RT_MAT_DIFFUSE) {
                         cr >>= 1; cg >>= 1; cb >>= 1;
