@@ -296,7 +296,8 @@ typedef enum rt_option {
     RT_OPT_CHUNKS_PER_WAVE = 7,   /* work queue granularity: a call whose 8x8-pixel tiles number fewer than this many
                                      per resident wave cuts each tile into 2 or 4 strips of rows and then its samples
                                      into segments, chunks of at least 256 paths; segments add into the frame with
-                                     atomics (0..256, default 32, 0 = never cut).  Results do not depend on it. */
+                                     atomics (0..256, default 32, 0 = never cut, except that a chunk never holds more than 256 samples
+                                     of a pixel).  Results do not depend on it. */
     RT_OPT_SUBTILES = 8,          /* most strips of rows a tile is cut into before its samples are: 1, 2 or 4 (default) */
     RT_OPT_DIRECT_ADD_SAMPLES = 10, /* calls (or cut chunks) of at most this many samples per pixel add every path's colour to the
                                      frame with atomics of its own instead of through per-chunk sums in LDS, so that a wave
