@@ -390,13 +390,13 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     a.aux_bytes = trace_aux_bytes(a.filter, a.bvh.levels, a.bvh.lds_nodes);
 
     a.stack_entry_bytes = a.n <= 65536u ? 2u : 4u;
-    size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
+    size_t lds = trace_lds_bytes(a.filter, a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
     if (lds > 64u * 1024u && a.bvh.lds_nodes != 0u) {
         // a copy of the nodes this large would leave room for one or two workgroups per CU:
         // walk them through the caches instead
         a.bvh.lds_nodes = 0u;
         a.aux_bytes = trace_aux_bytes(a.filter, a.bvh.levels, 0u);
-        lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
+        lds = trace_lds_bytes(a.filter, a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
     }
     if (lds > 160u * 1024u)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_depth too large: the bounce stack does not fit in LDS");

@@ -171,7 +171,7 @@ hipError_t static_scratch_address(void **ptr);
 // Bytes of LDS between the tiles and the bounce stack for `filter`.
 uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels, uint32_t bvh_lds_nodes);
 // Bytes of dynamic LDS the trace kernel needs.
-size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth, uint32_t stack_entry_bytes);
+size_t trace_lds_bytes(int filter, uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth, uint32_t stack_entry_bytes);
 
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream);
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream);

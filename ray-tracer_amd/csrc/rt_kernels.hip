@@ -192,7 +192,7 @@ enum { kPlain = 0, kExt = 1, kCount = 2 };
 // SPLIT: for the list scans, the list does not fit one LDS tile and is scanned tile by tile; for the
 // hierarchy scan (which has no tiles), the nodes are read from memory instead of from an LDS copy.
 template <bool SPLIT, int FILTER, int VARIANT>
-__global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? (VARIANT == kCount ? 5 : 7) : 4)
+__global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? (VARIANT == kCount ? 5 : 7) : (FILTER == kFilterMatrix && VARIANT != kCount ? 5 : 4))
 trace_kernel(const TraceArgs a)
 {
     constexpr bool EXT = VARIANT == kExt;
@@ -205,8 +205,10 @@ trace_kernel(const TraceArgs a)
     const unsigned long long t_start = VARIANT == kCount ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long t_mark = t_start;
     extern __shared__ __align__(16) unsigned char smem[];
+    // list scans: the tile's filter records, then its exact records -- except in the matrix scan, whose
+    // few candidates fetch their exact records from memory (8 KB of LDS less per 512 spheres)
     Geom *tile_f = reinterpret_cast<Geom *>(smem);
-    Geom *tile_e = tile_f + a.tile_cap;
+    Geom *tile_e = FILTER == kFilterMatrix ? tile_f : tile_f + a.tile_cap;
     // matrix scan: 4 waves x 9 x 64 floats of operand staging; hierarchy scan: the walk's
     // stack, levels x 256 node references
     float *stage = reinterpret_cast<float *>(tile_e + a.tile_cap);
@@ -225,7 +227,7 @@ trace_kernel(const TraceArgs a)
     const uint32_t n_pad = round_up_group(a.n);
 
     if (!MULTI_TILE && FILTER != kFilterBvh) {
-        load_tile(tile_f, tile_e, filt_src, a.exact, 0u, n_pad);
+        load_tile(tile_f, FILTER == kFilterMatrix ? nullptr : tile_e, filt_src, a.exact, 0u, n_pad);
         __syncthreads();
     }
     // hierarchy scan: the nodes of a small tree live in LDS, behind the walk's stack (whose entries
@@ -459,15 +461,15 @@ trace_kernel(const TraceArgs a)
             const uint32_t cnt = MULTI_TILE ? min(a.tile_cap, a.n - t0) : a.n;
             if (MULTI_TILE) {
                 __syncthreads(); // everyone is done with the previous tile (and with wave_flags)
-                load_tile(tile_f, tile_e, filt_src, a.exact, t0, round_up_group(cnt));
+                load_tile(tile_f, FILTER == kFilterMatrix ? nullptr : tile_e, filt_src, a.exact, t0, round_up_group(cnt));
                 __syncthreads();
             }
             if (FILTER == kFilterMatrix) {
                 if (wave_active)
-                    scan_tile_matrix(reinterpret_cast<const float *>(tile_f), tile_e, round_up_group(cnt), t0, mo,
+                    scan_tile_matrix(reinterpret_cast<const float *>(tile_f), a.exact + t0, round_up_group(cnt), t0, mo,
                                      ray, mine, lane, 0.001f, closest, best, wc);
                 if (active && !ray.tame) // NaN, Inf, zero or huge rays: the reference's in-order loop
-                    scan_tile<kFilterExact>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best, wc);
+                    scan_tile<kFilterExact>(a.exact + t0, a.exact + t0, cnt, t0, ray, 0.001f, closest, best, wc);
             } else if (active) {
                 if (FILTER == kFilterConservative && !MULTI_TILE && cnt <= kShortList) {
                     // a handful of spheres (the reference's own scene has four): its loop as it
@@ -930,10 +932,10 @@ uint32_t trace_aux_bytes(int filter, uint32_t bvh_levels, uint32_t bvh_lds_nodes
     return filter == kFilterMatrix ? 4u * 9u * 64u * (uint32_t)sizeof(float) : 4u * 64u;
 }
 
-size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth, uint32_t stack_entry_bytes)
+size_t trace_lds_bytes(int filter, uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth, uint32_t stack_entry_bytes)
 {
     const size_t levels = max_depth > 0 ? (size_t)max_depth : 1u;
-    return (size_t)tile_cap * 2u * sizeof(Geom) + aux_bytes +
+    return (size_t)tile_cap * (filter == kFilterMatrix ? 1u : 2u) * sizeof(Geom) + aux_bytes +
            levels * kTraceThreads * stack_entry_bytes + 4u * sizeof(uint32_t) +
            4u * 2u * 64u * 2u * sizeof(uint32_t);
 }
@@ -941,7 +943,7 @@ size_t trace_lds_bytes(uint32_t tile_cap, uint32_t aux_bytes, int32_t max_depth,
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream)
 {
     (void)hipGetLastError(); // a failure of some earlier, unrelated runtime call is not this launch\'s
-    const size_t lds = trace_lds_bytes(a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
+    const size_t lds = trace_lds_bytes(a.filter, a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
     // the kernels' SPLIT: a list in several tiles, or a hierarchy whose nodes stay in memory
     const bool multi = a.filter == kFilterBvh ? a.bvh.lds_nodes == 0u : a.n > a.tile_cap;
     const dim3 grid(n_workgroups), block(kTraceThreads);

@@ -236,10 +236,12 @@ __device__ __forceinline__ void scan_tile_matrix(const float *__restrict__ filt,
 __device__ __forceinline__ void load_tile(Geom *tile_f, Geom *tile_e, const Geom *__restrict__ filt,
                                           const Geom *__restrict__ exact, uint32_t t0, uint32_t cnt_padded)
 {
-    const float4 *src_e = reinterpret_cast<const float4 *>(exact + t0);
-    float4 *dst_e = reinterpret_cast<float4 *>(tile_e);
-    for (uint32_t i = threadIdx.x; i < cnt_padded; i += blockDim.x)
-        dst_e[i] = src_e[i];
+    if (tile_e) { // (null: the scan reads its exact records from memory)
+        const float4 *src_e = reinterpret_cast<const float4 *>(exact + t0);
+        float4 *dst_e = reinterpret_cast<float4 *>(tile_e);
+        for (uint32_t i = threadIdx.x; i < cnt_padded; i += blockDim.x)
+            dst_e[i] = src_e[i];
+    }
     if (filt) {
         const float4 *src_f = reinterpret_cast<const float4 *>(filt + t0);
         float4 *dst_f = reinterpret_cast<float4 *>(tile_f);
