@@ -78,7 +78,7 @@ struct rt_context {
     size_t io_out_bytes = 0;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr; // device time of the synchronous calls' kernels
     // resident workgroups per CU of the trace kernel, by (filter, LDS bytes): asked of the runtime once
-    struct OccEntry { int filter; size_t lds; int per_cu; };
+    struct OccEntry { int filter; bool counting; size_t lds; int per_cu; };
     std::vector<OccEntry> occupancy_cache;
 
     uint32_t tile_cap_max = 512;  // spheres per LDS tile (2 x 16 B each: 16 KiB; 4 workgroups per CU)
@@ -402,12 +402,12 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "max_depth too large: the bounce stack does not fit in LDS");
     int per_cu = 0;
     for (const rt_context::OccEntry &e : ctx->occupancy_cache)
-        if (e.filter == a.filter && e.lds == lds)
+        if (e.filter == a.filter && e.counting == (a.count_work != 0u) && e.lds == lds)
             per_cu = e.per_cu;
     if (per_cu == 0) {
-        RT_HIP(ctx, trace_occupancy(a.filter, lds, &per_cu));
+        RT_HIP(ctx, trace_occupancy(a.filter, a.count_work != 0u, lds, &per_cu));
         if (ctx->occupancy_cache.size() < 64u)
-            ctx->occupancy_cache.push_back({ a.filter, lds, per_cu });
+            ctx->occupancy_cache.push_back({ a.filter, a.count_work != 0u, lds, per_cu });
     }
     if (per_cu < 1)
         return fail(ctx, RT_ERR_HIP, "trace kernel does not fit on a CU");

@@ -181,6 +181,6 @@ hipError_t launch_add_sums(const AddArgs &a, hipStream_t stream);
 hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream);
 hipError_t launch_intersect(const IntersectArgs &a, hipStream_t stream);
 // Resident workgroups per CU of the trace kernel at this LDS size.
-hipError_t trace_occupancy(int filter, size_t lds_bytes, int *workgroups_per_cu);
+hipError_t trace_occupancy(int filter, bool counting, size_t lds_bytes, int *workgroups_per_cu);
 
 } // namespace rtamd

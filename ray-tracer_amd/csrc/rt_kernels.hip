@@ -204,6 +204,10 @@ trace_kernel(const TraceArgs a)
     WorkCount *const wc = VARIANT == kCount ? &work : nullptr;
     const unsigned long long t_start = VARIANT == kCount ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long t_mark = t_start;
+    // the chip-wide constant-rate clock (the shader clock's counters differ between the chip's dies):
+    // when the wave started and when it found the work queue empty
+    const unsigned long long t_wall = VARIANT == kCount ? wall_clock64() : 0ull;
+    unsigned long long t_dry = 0ull;
     extern __shared__ __align__(16) unsigned char smem[];
     // list scans: the tile's filter records, then its exact records -- except in the matrix scan, whose
     // few candidates fetch their exact records from memory (8 KB of LDS less per 512 spheres)
@@ -313,6 +317,8 @@ trace_kernel(const TraceArgs a)
                 RT_CLOCK(wc, kTimeFetch, t_fetch);
                 if (c >= kq->n_chunks) {
                     queue_empty = true;
+                    if (wc)
+                        t_dry = wall_clock64();
                     break;
                 }
                 uint32_t k = c, sub = 0u, seg = 0u;
@@ -712,11 +718,23 @@ trace_kernel(const TraceArgs a)
                 atomicAdd(counters + 9 + 2 * i, sl);
             }
         }
-        work.time[kTimeLife] = __builtin_amdgcn_s_memtime() - t_start;
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        work.time[kTimeLife] = t_end - t_start;
         if (lane == 0) { // [32 + i] cycles in phase i, [40] waves
             for (int i = 0; i < kTimeCount; ++i)
                 atomicAdd(counters + 32 + i, work.time[i]);
             atomicAdd(counters + 40, 1ull);
+            // When the waves started, found the queue empty and ended, on the chip-wide clock
+            // (its low 40 bits): sums in [41..43], and in the first slot alone (the host adds the
+            // slots up) the latest of each in [44..46] and the complement of the earliest in [47..49].
+            constexpr unsigned long long kLow = (1ull << 40) - 1ull;
+            const unsigned long long t_last = wall_clock64();
+            const unsigned long long at[3] = { t_wall & kLow, (t_dry ? t_dry : t_last) & kLow, t_last & kLow };
+            for (int i = 0; i < 3; ++i) {
+                atomicAdd(counters + 41 + i, at[i]);
+                atomicMax(a.rays + 44 + i, at[i]);
+                atomicMax(a.rays + 47 + i, kLow - at[i]);
+            }
         }
     }
 }
@@ -976,16 +994,20 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t trace_occupancy(int filter, size_t lds_bytes, int *workgroups_per_cu)
+hipError_t trace_occupancy(int filter, bool counting, size_t lds_bytes, int *workgroups_per_cu)
 {
+    // (the instantiations of one scan share their launch bound, the counting builds apart)
+#define RT_OCCUPANCY(FILTER)                                                                                   \
+    (counting ? hipOccupancyMaxActiveBlocksPerMultiprocessor(workgroups_per_cu, trace_kernel<false, FILTER, kCount>, \
+                                                             kTraceThreads, lds_bytes)                          \
+              : hipOccupancyMaxActiveBlocksPerMultiprocessor(workgroups_per_cu, trace_kernel<false, FILTER, kPlain>, \
+                                                             kTraceThreads, lds_bytes))
     if (filter == kFilterBvh)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            workgroups_per_cu, trace_kernel<false, kFilterBvh, kPlain>, kTraceThreads, lds_bytes);
+        return RT_OCCUPANCY(kFilterBvh);
     if (filter == kFilterMatrix)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            workgroups_per_cu, trace_kernel<false, kFilterMatrix, kPlain>, kTraceThreads, lds_bytes);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        workgroups_per_cu, trace_kernel<false, kFilterConservative, kPlain>, kTraceThreads, lds_bytes);
+        return RT_OCCUPANCY(kFilterMatrix);
+    return RT_OCCUPANCY(kFilterConservative);
+#undef RT_OCCUPANCY
 }
 
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream)

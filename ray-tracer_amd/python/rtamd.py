@@ -305,6 +305,12 @@ class Context:
         prof = {name: (int(out[2 * i]), int(out[2 * i + 1])) for i, name in enumerate(self.SECTIONS)}
         prof["cycles"] = dict(zip(["life", "fetch", "refill", "scan", "points", "shade", "flush"], [int(v) for v in out[24:31]]))
         prof["cycles"]["waves"] = int(out[32])
+        # per wave: start, queue found empty, end (cycles of the chip's clock after the first wave's start)
+        low, waves = (1 << 40) - 1, max(int(out[32]), 1)
+        first = low - int(out[39])
+        prof["timeline"] = {name: {"mean": int(out[33 + i]) / waves - first, "first": low - int(out[39 + i]) - first,
+                                   "last": int(out[36 + i]) - first}
+                            for i, name in enumerate(["start", "queue_empty", "end"])}
         return prof
 
 

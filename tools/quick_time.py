@@ -20,15 +20,20 @@ CASES = [
     ("c5 hierarchy 1080p/64", scenes.random_spheres(10000, grid_half=50), cam3, rtamd.FILTER_AUTO, (1920, 1080, 64, 8)),
     ("c3 hierarchy 1080p/4", scenes.random_spheres(500), cam3, rtamd.FILTER_AUTO, (1920, 1080, 4, 8)),
     ("c3 hierarchy 1080p/1", scenes.random_spheres(500), cam3, rtamd.FILTER_AUTO, (1920, 1080, 1, 8)),
+    ("c3 hierarchy 1080p/8", scenes.random_spheres(500), cam3, rtamd.FILTER_AUTO, (1920, 1080, 8, 8)),
+    ("c3 hierarchy 1080p/16", scenes.random_spheres(500), cam3, rtamd.FILTER_AUTO, (1920, 1080, 16, 8)),
+    # one rank's share of the 64 spp frame split over 8 devices by tiles
+    ("c3 hierarchy 1080p/64 tiles 3 mod 8", scenes.random_spheres(500), cam3, rtamd.FILTER_AUTO, (1920, 1080, 64, 8),
+     dict(tile_first=3, tile_stride=8)),
 ]
 only = os.environ.get("QT_ONLY")
 ctx = rtamd.Context(0)
-for name, scene, cam, filt, (W, H, spp, depth) in CASES:
+for name, scene, cam, filt, (W, H, spp, depth), *share in CASES:
     if only and only not in name:
         continue
     ctx.set_option(rtamd.OPT_FILTER, filt)
     ctx.set_scene(scene)
-    p = rtamd.params(W, H, spp, depth, seed=1)
+    p = rtamd.params(W, H, spp, depth, seed=1, **(share[0] if share else {}))
     d = torch.zeros(W * H * 3, dtype=torch.int32, device="cuda")
     ctx.reset_stats()
     ctx.accumulate_device(cam, p, d.data_ptr())
@@ -44,5 +49,5 @@ for name, scene, cam, filt, (W, H, spp, depth) in CASES:
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1))
     t = float(np.median(times))
-    print(f"{name:26s} {t:8.3f} ms (min {min(times):.3f})  {rays / t / 1e6:8.2f} Grays/s  rays {rays}  crc {crc:08x}", flush=True)
+    print(f"{name:36s} {t:8.3f} ms (min {min(times):.3f})  {rays / t / 1e6:8.2f} Grays/s  rays {rays}  crc {crc:08x}", flush=True)
 ctx.close()
