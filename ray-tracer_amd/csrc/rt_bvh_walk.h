@@ -55,7 +55,7 @@ __device__ __forceinline__ void test_records(const BvhArgs &b, const RayState &r
         RT_TALLY(wc, kSecLeafGroup);
 #pragma unroll
         for (uint32_t j = 0u; j < 4u; ++j)
-            g[j] = b.leaf_geom[first + i0 + j];
+            g[j] = *reinterpret_cast<const Geom *>(reinterpret_cast<const char *>(b.leaf_geom) + ((first + i0) << 4) + 16u * j);
         float Bj[4], dj[4];
         uint32_t cand = 0u;
 #pragma unroll
@@ -201,7 +201,11 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
             if (wc)
                 ++wc->nodes;
             RT_TALLY(wc, kSecNode);
-            const float4 *np = (NODES_IN_LDS ? lds_nodes : b.nodes) + (size_t)node * 4u;
+            // (a tree in memory: the node's byte offset as an unsigned 32-bit number, which the load
+            // takes next to the array's address in scalar registers -- no 64-bit address arithmetic)
+            const float4 *np = NODES_IN_LDS ? lds_nodes + (size_t)node * 4u
+                                            : reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(b.nodes) +
+                                                                               ((uint32_t)node << 6));
             const float4 l0 = np[0], h0 = np[1], l1 = np[2], h1 = np[3];
 #define RT_SLAB(lo, hi, na, nb, nc) __builtin_fmaf(lo, na, __builtin_fmaf(hi, nb, nc))
             const float n0 = fmaxf(fmaxf(fmaxf(RT_SLAB(l0.x, h0.x, nax, nbx, ncx), RT_SLAB(l0.y, h0.y, nay, nby, ncy)),
