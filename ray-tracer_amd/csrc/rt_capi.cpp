@@ -385,8 +385,10 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     // LDS tile: the whole (padded) list when it fits, else tiles of tile_cap_max
     const uint32_t n_pad = (a.n + (kPad - 1)) & ~(uint32_t)(kPad - 1);
     a.tile_cap = n_pad <= ctx->tile_cap_max ? (n_pad ? n_pad : kPad) : ctx->tile_cap_max;
-    if (a.filter == kFilterBvh)
-        a.tile_cap = 0u; // the walk reads nodes and leaf records from memory
+    if (a.filter == kFilterConservative && a.n <= kShortList)
+        a.filter = kFilterShort;
+    if (a.filter == kFilterBvh || a.filter == kFilterShort)
+        a.tile_cap = 0u; // the walk reads nodes and leaf records from memory, the short list is read with scalar loads
     a.aux_bytes = trace_aux_bytes(a.filter, a.bvh.levels, a.bvh.lds_nodes);
 
     a.stack_entry_bytes = a.n <= 65536u ? 2u : 4u;

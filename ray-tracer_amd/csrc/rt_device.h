@@ -40,8 +40,14 @@ enum {
     kFilterExact = 0,        // the reference's own discriminant, unfused, on the vector ALU
     kFilterConservative = 1, // fused, widened test on the vector ALU: superset of the exact candidates
     kFilterMatrix = 2,       // the widened test as two 4-term products on the FP32 matrix cores
-    kFilterBvh = 3           // per-ray walk of a box hierarchy; the spheres in the leaves reached are candidates
+    kFilterBvh = 3,          // per-ray walk of a box hierarchy; the spheres in the leaves reached are candidates
+    // Not selectable: what kFilterConservative becomes for a list of at most kShortList spheres (the
+    // reference's own scene has four) -- the reference's loop as it stands, Source/main.cpp:534-546,
+    // over records read with scalar loads, in a kernel of its own that holds no tile and none of the
+    // block filter's registers, so that seven waves per SIMD fit instead of four.
+    kFilterShort = 4
 };
+constexpr uint32_t kShortList = 12u;
 
 // Most samples of a pixel in one work-queue chunk: a wave keeps a chunk's per-pixel sums in 16 bits per
 // channel, and a sample adds at most 255.

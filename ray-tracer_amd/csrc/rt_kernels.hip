@@ -37,7 +37,6 @@ namespace rtamd {
 namespace {
 
 // Lists up to this long are scanned by the reference's plain loop in the vector-scan kernel.
-constexpr uint32_t kShortList = 12u;
 
 // The bounce stack holds list indices: two bytes per entry while the list has at most 65536
 // spheres, else four.
@@ -192,14 +191,14 @@ enum { kPlain = 0, kExt = 1, kCount = 2 };
 // SPLIT: for the list scans, the list does not fit one LDS tile and is scanned tile by tile; for the
 // hierarchy scan (which has no tiles), the nodes are read from memory instead of from an LDS copy.
 template <bool SPLIT, int FILTER, int VARIANT>
-__global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh ? (VARIANT == kCount ? 5 : 7) : (FILTER == kFilterMatrix && VARIANT != kCount ? 5 : 4))
+__global__ void __launch_bounds__(kTraceThreads, FILTER == kFilterBvh || FILTER == kFilterShort ? (VARIANT == kCount ? 5 : 7) : (FILTER == kFilterMatrix && VARIANT != kCount ? 5 : 4))
 trace_kernel(const TraceArgs a)
 {
     constexpr bool EXT = VARIANT == kExt;
     constexpr bool MULTI_TILE = SPLIT && FILTER != kFilterBvh;
     constexpr bool NODES_IN_LDS = !SPLIT && FILTER == kFilterBvh;
     // a tree in LDS has at most 2048 records: its bounce stack entries take two bytes, known here
-    const uint32_t bounce_bytes = NODES_IN_LDS ? 2u : a.stack_entry_bytes;
+    const uint32_t bounce_bytes = NODES_IN_LDS || FILTER == kFilterShort ? 2u : a.stack_entry_bytes;
     WorkCount work = {};
     WorkCount *const wc = VARIANT == kCount ? &work : nullptr;
     const unsigned long long t_start = VARIANT == kCount ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -230,7 +229,7 @@ trace_kernel(const TraceArgs a)
     const int wave = tid >> 6;
     const uint32_t n_pad = round_up_group(a.n);
 
-    if (!MULTI_TILE && FILTER != kFilterBvh) {
+    if (!MULTI_TILE && FILTER != kFilterBvh && FILTER != kFilterShort) {
         load_tile(tile_f, FILTER == kFilterMatrix ? nullptr : tile_e, filt_src, a.exact, 0u, n_pad);
         __syncthreads();
     }
@@ -463,7 +462,28 @@ trace_kernel(const TraceArgs a)
                 shade = false; // still walking: continues in the next pass
             }
         }
-        for (uint32_t t0 = 0u; FILTER != kFilterBvh && t0 < (MULTI_TILE ? a.n : 1u); t0 += a.tile_cap) {
+        if (FILTER == kFilterShort && active) {
+            // the same records for every lane, never written while a kernel runs: scalar loads
+            typedef const __attribute__((address_space(4))) float *ConstFloats;
+            const ConstFloats eg = (ConstFloats)a.exact;
+            // four records per round of loads (the array is padded far beyond the list's end)
+            for (uint32_t i0 = 0u; i0 < a.n; i0 += 4u) {
+                float rec[16];
+#pragma unroll
+                for (uint32_t q = 0u; q < 16u; ++q)
+                    rec[q] = eg[4u * i0 + q];
+#pragma unroll
+                for (uint32_t j = 0u; j < 4u; ++j) {
+                    if (i0 + j < a.n) {
+                        Geom g;
+                        g.cx = rec[4u * j + 0u]; g.cy = rec[4u * j + 1u]; g.cz = rec[4u * j + 2u]; g.r2 = rec[4u * j + 3u];
+                        if (resolve_candidate(ray, g, 0.001f, closest, wc))
+                            best = (int)(i0 + j);
+                    }
+                }
+            }
+        }
+        for (uint32_t t0 = 0u; FILTER != kFilterBvh && FILTER != kFilterShort && t0 < (MULTI_TILE ? a.n : 1u); t0 += a.tile_cap) {
             const uint32_t cnt = MULTI_TILE ? min(a.tile_cap, a.n - t0) : a.n;
             if (MULTI_TILE) {
                 __syncthreads(); // everyone is done with the previous tile (and with wave_flags)
@@ -477,15 +497,7 @@ trace_kernel(const TraceArgs a)
                 if (active && !ray.tame) // NaN, Inf, zero or huge rays: the reference's in-order loop
                     scan_tile<kFilterExact>(a.exact + t0, a.exact + t0, cnt, t0, ray, 0.001f, closest, best, wc);
             } else if (active) {
-                if (FILTER == kFilterConservative && !MULTI_TILE && cnt <= kShortList) {
-                    // a handful of spheres (the reference's own scene has four): its loop as it
-                    // stands, :534-546 -- cheaper than a 32-record filter block that is mostly padding
-                    for (uint32_t i = 0u; i < cnt; ++i)
-                        if (resolve_candidate(ray, tile_e[i], 0.001f, closest, wc))
-                            best = (int)i;
-                } else {
-                    scan_tile<FILTER>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best, wc);
-                }
+                scan_tile<FILTER>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best, wc);
             }
         }
         if (wave_active)
@@ -963,7 +975,7 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
     (void)hipGetLastError(); // a failure of some earlier, unrelated runtime call is not this launch\'s
     const size_t lds = trace_lds_bytes(a.filter, a.tile_cap, a.aux_bytes, a.max_depth, a.stack_entry_bytes);
     // the kernels' SPLIT: a list in several tiles, or a hierarchy whose nodes stay in memory
-    const bool multi = a.filter == kFilterBvh ? a.bvh.lds_nodes == 0u : a.n > a.tile_cap;
+    const bool multi = a.filter == kFilterBvh ? a.bvh.lds_nodes == 0u : a.filter != kFilterShort && a.n > a.tile_cap;
     const dim3 grid(n_workgroups), block(kTraceThreads);
     const bool glass = (a.flags & (RT_FLAG_DIELECTRIC | RT_FLAG_FLOAT_SHADING)) != 0u; // the extended kernels
     const bool count = a.count_work != 0u && !glass; // tallies exist for the reference's behaviour only
@@ -987,6 +999,7 @@ hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t s
     case kFilterConservative: RT_LAUNCH_TRACE(kFilterConservative); break;
     case kFilterMatrix: RT_LAUNCH_TRACE(kFilterMatrix); break;
     case kFilterBvh: RT_LAUNCH_TRACE(kFilterBvh); break;
+    case kFilterShort: RT_LAUNCH_TRACE(kFilterShort); break;
     default:
         return hipErrorInvalidValue;
     }
@@ -1006,6 +1019,8 @@ hipError_t trace_occupancy(int filter, bool counting, size_t lds_bytes, int *wor
         return RT_OCCUPANCY(kFilterBvh);
     if (filter == kFilterMatrix)
         return RT_OCCUPANCY(kFilterMatrix);
+    if (filter == kFilterShort)
+        return RT_OCCUPANCY(kFilterShort);
     return RT_OCCUPANCY(kFilterConservative);
 #undef RT_OCCUPANCY
 }

@@ -208,6 +208,31 @@ def test_matrix_filter_on_a_four_sphere_scene(ctx):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n", [1, 4, 5, 11, 12, 13])
+def test_lists_around_the_short_list_kernels_limit(ctx, n):
+    """Up to 12 spheres the vector scan is the reference's loop over scalar-loaded records in a kernel of
+    its own, from 13 on the block filter over an LDS tile: both sides of the switch against the oracle,
+    with a duplicated sphere (ties go to the later one, Source/main.cpp:534-546) and the extension kernel."""
+    rs = np.random.RandomState(100 + n)
+    sc = np.zeros(n, dtype=rtamd.SPHERE_DTYPE)
+    sc["center"] = rs.uniform(-2.5, 2.5, size=(n, 3)).astype(np.float32) + np.array([0, 0, -4], dtype=np.float32)
+    sc["radius"] = rs.uniform(0.3, 1.2, size=n).astype(np.float32)
+    sc["material"] = rs.randint(0, 4, size=n)
+    sc["color"] = np.where((sc["material"] == 1)[:, None], rs.uniform(0, 255, (n, 3)), rs.uniform(0, 1, (n, 3)))
+    sc["fuzz"] = rs.uniform(0, 1, size=n)
+    if n >= 4:
+        sc[n - 1] = sc[1]
+    ctx.set_scene(sc)
+    for flags in (0, rtamd.FLAG_DIELECTRIC | rtamd.FLAG_GAMMA2):
+        want, _, rays = O.trace_tile(sc, O.default_camera(), 80, 45, 5, 9, O.RNG_COUNTER, seed=n, flags=flags)
+        for filt in (rtamd.FILTER_AUTO, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_EXACT):
+            ctx.set_option(rtamd.OPT_FILTER, filt)
+            ctx.reset_stats()
+            got = ctx.render(rtamd.default_camera(), rtamd.params(80, 45, 5, 9, seed=n, flags=flags))
+            assert np.array_equal(got, want) and ctx.stats().rays == rays, (n, flags, filt)
+    ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
+
+
 def test_matrix_filter_far_from_origin_and_degenerate_paths(ctx):
     """The matrix filter expands about the scene's median centre; a scene 5000 units away from the
     origin, with a tiny and a huge sphere mixed in, must still match the oracle bit for bit."""
