@@ -175,7 +175,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *par
  * file-scope device array of the library instead of buffers the context grows on demand, and the
  * call allocates and frees nothing (no hipMalloc, no hipFree).  Limits and rules:
  *   - width * height <= RT_STATIC_MAX_PIXELS, else RT_ERR_INVALID_ARGUMENT;
- *   - each GPU the library runs on holds its own copy of the array (24 MiB + 2 KiB) until the
+ *   - each GPU the library runs on holds its own copy of the array (24 MiB + 16 KiB) until the
  *     process ends, and ALL contexts on one GPU share it: calls that overlap in time on one GPU race
  *     (calls on one context are ordered by the library, whatever their streams);
  *   - the scan's device data must exist already: rt_set_scene and rt_set_option put the hierarchy
