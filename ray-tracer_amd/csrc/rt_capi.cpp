@@ -72,6 +72,8 @@ struct rt_context {
     size_t sums_bytes = 0;
     uint8_t *d_rgb = nullptr;   // scratch for rt_render
     size_t rgb_bytes = 0;
+    uint8_t *h_rows = nullptr;  // pinned host staging for regions narrower than the frame
+    size_t rows_bytes = 0;
     void *d_io_in = nullptr;    // scratch for rt_intersect's rays
     size_t io_in_bytes = 0;
     void *d_io_out = nullptr;   // scratch for rt_intersect's records and rt_primary_hits' map
@@ -547,6 +549,7 @@ int rt_destroy(rt_context *ctx)
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+    if (ctx->h_rows) (void)hipHostFree(ctx->h_rows);
     if (ctx->d_io_in) (void)hipFree(ctx->d_io_in);
     if (ctx->d_io_out) (void)hipFree(ctx->d_io_out);
     if (ctx->ev_trace) (void)hipEventDestroy(ctx->ev_trace);
@@ -780,6 +783,39 @@ static int render_device(rt_context *ctx, const rt_camera *cam, const rt_params 
     return RT_OK;
 }
 
+// Copies region `rg` of the device frame into the host frame of the same layout, behind the work
+// enqueued on `stream`, and waits for it.  A pitched copy to pageable memory is carried out row by
+// row (8.6 ms for a 1080p frame against 0.6 for one run of bytes), so rows that span the frame's width
+// go as one contiguous copy, and a narrower region's rows are fetched whole into pinned staging
+// memory and their part of interest copied out by the host.
+static int copy_region_to_host(rt_context *ctx, uint8_t *rgb, const uint8_t *d_rgb, uint32_t width, const Region &rg,
+                               hipStream_t stream)
+{
+    const size_t pitch = (size_t)width * 3u;
+    const size_t row0 = (size_t)rg.y0 * pitch;
+    if ((uint32_t)rg.w == width) {
+        RT_HIP(ctx, hipMemcpyAsync(rgb + row0, d_rgb + row0, (size_t)rg.h * pitch, hipMemcpyDeviceToHost, stream));
+        RT_HIP(ctx, hipStreamSynchronize(stream));
+        return RT_OK;
+    }
+    const size_t want = (size_t)rg.h * pitch;
+    if (ctx->rows_bytes < want) {
+        if (ctx->h_rows)
+            RT_HIP(ctx, hipHostFree(ctx->h_rows));
+        ctx->h_rows = nullptr;
+        ctx->rows_bytes = 0;
+        if (hipHostMalloc((void **)&ctx->h_rows, want, hipHostMallocDefault) != hipSuccess)
+            return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipHostMalloc failed for the copy-back staging");
+        ctx->rows_bytes = want;
+    }
+    RT_HIP(ctx, hipMemcpyAsync(ctx->h_rows, d_rgb + row0, want, hipMemcpyDeviceToHost, stream));
+    RT_HIP(ctx, hipStreamSynchronize(stream));
+    const size_t x_off = (size_t)rg.x0 * 3u, run = (size_t)rg.w * 3u;
+    for (int r = 0; r < rg.h; ++r)
+        memcpy(rgb + row0 + (size_t)r * pitch + x_off, ctx->h_rows + (size_t)r * pitch + x_off, run);
+    return RT_OK;
+}
+
 int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
                      int ystart, int xsize, int ysize, uint8_t *d_rgb, void *stream)
 {
@@ -818,19 +854,13 @@ int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, in
     st = rt_render_device(ctx, cam, params, xstart, ystart, xsize, ysize, ctx->d_rgb, ctx->stream);
     if (st == RT_OK) {
         hipError_t e = hipEventRecord(e1, ctx->stream);
-        const size_t pitch = (size_t)params->width * 3u;
-        const size_t off = ((size_t)rg.x0 + (size_t)rg.y0 * params->width) * 3u;
-        if (e == hipSuccess)
-            e = hipMemcpy2DAsync(rgb + off, pitch, ctx->d_rgb + off, pitch, (size_t)rg.w * 3u, (size_t)rg.h,
-                                 hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
-                ctx->last_kernel_ms = ms;
+        if (e != hipSuccess) {
+            st = fail_hip(ctx, e, "rt_render");
         } else {
-            st = fail_hip(ctx, e, "rt_render copy-back");
+            st = copy_region_to_host(ctx, rgb, ctx->d_rgb, params->width, rg, ctx->stream);
+            float ms = 0.f;
+            if (st == RT_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+                ctx->last_kernel_ms = ms;
         }
     }
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -867,8 +897,6 @@ int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params
         RT_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_trace, 0));
     const size_t row_bytes = (size_t)params->width * 3u * sizeof(uint32_t);
     RT_HIP(ctx, hipMemsetAsync((uint8_t *)ctx->d_sums + (size_t)rg.y0 * row_bytes, 0, (size_t)rg.h * row_bytes, s));
-    const size_t pitch = (size_t)params->width * 3u;
-    const size_t off = ((size_t)rg.x0 + (size_t)rg.y0 * params->width) * 3u;
     for (uint32_t done = 0; done < params->spp;) {
         rt_params pass = *params;
         pass.sample_begin = done;
@@ -883,9 +911,9 @@ int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params
         a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
         RT_HIP(ctx, launch_resolve(a, s));
         RT_HIP(ctx, hipEventRecord(ctx->ev_trace, s));
-        RT_HIP(ctx, hipMemcpy2DAsync(rgb + off, pitch, ctx->d_rgb + off, pitch, (size_t)rg.w * 3u, (size_t)rg.h,
-                                     hipMemcpyDeviceToHost, s));
-        RT_HIP(ctx, hipStreamSynchronize(s));
+        st = copy_region_to_host(ctx, rgb, ctx->d_rgb, params->width, rg, s);
+        if (st != RT_OK)
+            return st;
         if (progress && progress(user, done, params->spp) != 0)
             break;
     }
