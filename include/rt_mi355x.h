@@ -159,7 +159,9 @@ int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *params, in
  * display frame, Source/main.cpp:302-305).  This variant traces `samples_per_pass` samples at a
  * time; after each pass the tile in `rgb` holds the average of the samples so far and `progress`
  * (may be NULL) is called; a non-zero return stops the render (RT_OK, partial average kept).
- * After the last pass `rgb` equals rt_render's output. */
+ * After the last pass `rgb` equals rt_render's output.  The next pass is traced while a pass's
+ * frame travels to the host and `progress` runs, so a stop takes effect one pass late: that pass
+ * is traced (and counted in rt_stats) but never shown. */
 typedef int (*rt_progress_fn)(void *user, uint32_t samples_done, uint32_t samples_total);
 int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params *params, int xstart,
                           int ystart, int xsize, int ysize, uint8_t *rgb, uint32_t samples_per_pass,

@@ -74,6 +74,12 @@ struct rt_context {
     size_t rgb_bytes = 0;
     uint8_t *h_rows = nullptr;  // pinned host staging for regions narrower than the frame
     size_t rows_bytes = 0;
+    // rt_render_progressive: a second frame, a copy stream and "frame resolved" events, so that the
+    // next pass is traced while the last one's frame travels to the host and the callback runs
+    uint8_t *d_rgb2 = nullptr;
+    size_t rgb2_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_resolved[2] = { nullptr, nullptr };
     void *d_io_in = nullptr;    // scratch for rt_intersect's rays
     size_t io_in_bytes = 0;
     void *d_io_out = nullptr;   // scratch for rt_intersect's records and rt_primary_hits' map
@@ -550,6 +556,10 @@ int rt_destroy(rt_context *ctx)
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
     if (ctx->h_rows) (void)hipHostFree(ctx->h_rows);
+    if (ctx->d_rgb2) (void)hipFree(ctx->d_rgb2);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (hipEvent_t e : ctx->ev_resolved)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->d_io_in) (void)hipFree(ctx->d_io_in);
     if (ctx->d_io_out) (void)hipFree(ctx->d_io_out);
     if (ctx->ev_trace) (void)hipEventDestroy(ctx->ev_trace);
@@ -892,31 +902,66 @@ int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params
     const Region rg = clip_region(*params, xstart, ystart, xsize, ysize);
     if (rg.w == 0 || rg.h == 0)
         return RT_OK;
+    const bool pipelined = samples_per_pass < params->spp; // more than one pass
+    if (pipelined) {
+        st = ensure(ctx, (void **)&ctx->d_rgb2, &ctx->rgb2_bytes, frame_bytes);
+        if (st != RT_OK)
+            return st;
+        if (!ctx->copy_stream)
+            RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t &e : ctx->ev_resolved)
+            if (!e)
+                RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     hipStream_t s = ctx->stream;
     if (ctx->trace_enqueued) // the sums are shared scratch: behind their previous user, as in rt_render_device
         RT_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_trace, 0));
     const size_t row_bytes = (size_t)params->width * 3u * sizeof(uint32_t);
     RT_HIP(ctx, hipMemsetAsync((uint8_t *)ctx->d_sums + (size_t)rg.y0 * row_bytes, 0, (size_t)rg.h * row_bytes, s));
-    for (uint32_t done = 0; done < params->spp;) {
+    // Pass k's frame is resolved into one of two device frames and fetched on the copy stream; pass
+    // k + 1 is enqueued before the host waits for that copy and calls back, so the device traces
+    // while the frame travels and the caller looks at it.  (A callback that stops the render does
+    // so one enqueued pass late: that pass runs, its samples are never shown.)
+    auto enqueue_pass = [&](uint32_t begin) -> int {
         rt_params pass = *params;
-        pass.sample_begin = done;
-        pass.sample_count = std::min(samples_per_pass, params->spp - done);
-        st = enqueue_accumulate(ctx, cam, &pass, rg, ctx->d_sums, s);
-        if (st != RT_OK)
-            return st;
-        done += pass.sample_count;
+        pass.sample_begin = begin;
+        pass.sample_count = std::min(samples_per_pass, params->spp - begin);
+        return enqueue_accumulate(ctx, cam, &pass, rg, ctx->d_sums, s);
+    };
+    st = enqueue_pass(0u);
+    if (st != RT_OK)
+        return st;
+    uint32_t k = 0u;
+    for (uint32_t done = 0; done < params->spp; ++k) {
+        done += std::min(samples_per_pass, params->spp - done);
+        uint8_t *frame = (k & 1u) ? ctx->d_rgb2 : ctx->d_rgb;
         ResolveArgs a;
-        a.sums = ctx->d_sums; a.rgb = ctx->d_rgb;
+        a.sums = ctx->d_sums; a.rgb = frame;
         a.width = params->width; a.height = params->height; a.spp_div = done; a.flags = params->flags;
         a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
         RT_HIP(ctx, launch_resolve(a, s));
+        hipStream_t cs = s;
+        if (pipelined) {
+            cs = ctx->copy_stream;
+            RT_HIP(ctx, hipEventRecord(ctx->ev_resolved[k & 1u], s));
+            RT_HIP(ctx, hipStreamWaitEvent(cs, ctx->ev_resolved[k & 1u], 0));
+            if (done < params->spp) {
+                st = enqueue_pass(done);
+                if (st != RT_OK)
+                    break;
+            }
+        }
         RT_HIP(ctx, hipEventRecord(ctx->ev_trace, s));
-        st = copy_region_to_host(ctx, rgb, ctx->d_rgb, params->width, rg, s);
+        st = copy_region_to_host(ctx, rgb, frame, params->width, rg, cs);
         if (st != RT_OK)
-            return st;
+            break;
         if (progress && progress(user, done, params->spp) != 0)
             break;
     }
+    if (pipelined) // a pass enqueued ahead of a stop, or of a failure
+        RT_HIP(ctx, hipStreamSynchronize(s));
+    if (st != RT_OK)
+        return st;
     ctx->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
 }
