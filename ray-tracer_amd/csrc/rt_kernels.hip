@@ -33,6 +33,10 @@
 #include "rt_device.h"
 #include "rt_list_scan.h"
 
+#ifndef RT_REFILL_MIN_WALK
+#define RT_REFILL_MIN_WALK 24u
+#endif
+
 namespace rtamd {
 namespace {
 
@@ -197,6 +201,8 @@ trace_kernel(const TraceArgs a)
     constexpr bool EXT = VARIANT == kExt;
     constexpr bool MULTI_TILE = SPLIT && FILTER != kFilterBvh;
     constexpr bool NODES_IN_LDS = !SPLIT && FILTER == kFilterBvh;
+    // (a pass of the list scans costs as much with one lane as with 64: they refill every idle lane at once)
+    constexpr uint32_t kRefillMin = FILTER == kFilterBvh || FILTER == kFilterShort ? RT_REFILL_MIN_WALK : 1u;
     // a tree in LDS has at most 2048 records: its bounce stack entries take two bytes, known here
     const uint32_t bounce_bytes = NODES_IN_LDS || FILTER == kFilterShort ? 2u : a.stack_entry_bytes;
     WorkCount work = {};
@@ -288,7 +294,13 @@ trace_kernel(const TraceArgs a)
     for (;;) {
         // ---- refill idle lanes from the wave's chunk, pulling new chunks as needed
         unsigned long long need = idle_lanes;
-        while (need != 0ull && !queue_empty) {
+        // Idle lanes are refilled only once there are kRefillMin of them (or the wave holds no path):
+        // the refill -- a Philox block and the camera ray in double -- costs the wave the same for one
+        // lane as for 64, and a pass of the walking kernels is cheap enough that running a few of them
+        // with some lanes empty costs less than refilling every pass.  Which pass a path starts in
+        // does not enter its arithmetic.
+        const bool refill_now = (uint32_t)__popcll(need) >= kRefillMin;
+        while (need != 0ull && !queue_empty && refill_now) {
             if (w_next >= w_end) {
                 const ConstArgs kq = fresh_args(); // the call's shape is needed once per chunk: not worth registers
                 // a new chunk needs a free accumulator slot; with both in use the idle lanes
