@@ -36,6 +36,9 @@
 #ifndef RT_REFILL_MIN_WALK
 #define RT_REFILL_MIN_WALK 24u
 #endif
+#ifndef RT_REFILL_MIN_LIST
+#define RT_REFILL_MIN_LIST 1u
+#endif
 
 namespace rtamd {
 namespace {
@@ -202,7 +205,7 @@ trace_kernel(const TraceArgs a)
     constexpr bool MULTI_TILE = SPLIT && FILTER != kFilterBvh;
     constexpr bool NODES_IN_LDS = !SPLIT && FILTER == kFilterBvh;
     // (a pass of the list scans costs as much with one lane as with 64: they refill every idle lane at once)
-    constexpr uint32_t kRefillMin = FILTER == kFilterBvh || FILTER == kFilterShort ? RT_REFILL_MIN_WALK : 1u;
+    constexpr uint32_t kRefillMin = FILTER == kFilterBvh || FILTER == kFilterShort ? RT_REFILL_MIN_WALK : RT_REFILL_MIN_LIST;
     // a tree in LDS has at most 2048 records: its bounce stack entries take two bytes, known here
     const uint32_t bounce_bytes = NODES_IN_LDS || FILTER == kFilterShort ? 2u : a.stack_entry_bytes;
     WorkCount work = {};
