@@ -36,6 +36,9 @@
 #ifndef RT_REFILL_MIN_WALK
 #define RT_REFILL_MIN_WALK 24u
 #endif
+#ifndef RT_SHADE_MIN_WALK
+#define RT_SHADE_MIN_WALK 32u
+#endif
 #ifndef RT_REFILL_MIN_LIST
 #define RT_REFILL_MIN_LIST 1u
 #endif
@@ -206,6 +209,8 @@ trace_kernel(const TraceArgs a)
     constexpr bool NODES_IN_LDS = !SPLIT && FILTER == kFilterBvh;
     // (a pass of the list scans costs as much with one lane as with 64: they refill every idle lane at once)
     constexpr uint32_t kRefillMin = FILTER == kFilterBvh || FILTER == kFilterShort ? RT_REFILL_MIN_WALK : RT_REFILL_MIN_LIST;
+    // (a tree walked in memory makes the pass too dear for rays to sit one out: measured no gain)
+    constexpr uint32_t kShadeMin = NODES_IN_LDS ? RT_SHADE_MIN_WALK : 0u;
     // a tree in LDS has at most 2048 records: its bounce stack entries take two bytes, known here
     const uint32_t bounce_bytes = NODES_IN_LDS || FILTER == kFilterShort ? 2u : a.stack_entry_bytes;
     WorkCount work = {};
@@ -292,6 +297,7 @@ trace_kernel(const TraceArgs a)
     uint32_t w_sp = 0u;
     float w_closest = INFINITY;
     bool w_pending = false;
+    bool waited_last = false; // wave-uniform: the hit rays of the last pass were made to wait
 
     unsigned long long idle_lanes = ~0ull; // the lanes without a path (= !active), kept as a lane mask too
     for (;;) {
@@ -475,6 +481,26 @@ trace_kernel(const TraceArgs a)
                 best = w_best;
             } else {
                 shade = false; // still walking: continues in the next pass
+            }
+            // Hit rays wait a pass for company when fewer than kShadeMin of them are ready: drawing the
+            // random points and scattering cost the wave the same for a few lanes as for 64 (two or three
+            // Philox blocks, the hit frame's divisions), and the rays still walking or about to be
+            // refilled join them in the next pass.  A waiting ray keeps its finished walk (w_node stays
+            // kBvhDone, w_closest and w_best hold the hit).  Never two passes in a row, and only while
+            // other rays are on their way, so every path advances.
+            if (kShadeMin != 0u) {
+                const uint32_t n_hit = (uint32_t)__popcll(wave_ballot(shade && best >= 0));
+                const uint32_t n_walk = (uint32_t)__popcll(wave_ballot(active && !shade));
+                const uint32_t n_free = queue_empty ? 0u : 64u - n_hit - n_walk; // idle, or about to end in the sky
+                if (n_hit != 0u && n_hit < kShadeMin && !waited_last && n_walk + n_free >= 8u) {
+                    if (shade && best >= 0) {
+                        shade = false;
+                        w_pending = true;
+                    }
+                    waited_last = true;
+                } else {
+                    waited_last = false;
+                }
             }
         }
         if (FILTER == kFilterShort && active) {
