@@ -33,6 +33,8 @@
 #include "rt_device.h"
 #include "rt_list_scan.h"
 
+// Scheduling thresholds of the path kernel (lanes of a wave; overridable for sweeps): idle lanes before the
+// walking kernels refill, hit rays before they are shaded, idle lanes before the list scans refill.
 #ifndef RT_REFILL_MIN_WALK
 #define RT_REFILL_MIN_WALK 24u
 #endif
@@ -211,6 +213,9 @@ trace_kernel(const TraceArgs a)
     constexpr uint32_t kRefillMin = FILTER == kFilterBvh || FILTER == kFilterShort ? RT_REFILL_MIN_WALK : RT_REFILL_MIN_LIST;
     // (a tree walked in memory makes the pass too dear for rays to sit one out: measured no gain)
     constexpr uint32_t kShadeMin = NODES_IN_LDS ? RT_SHADE_MIN_WALK : 0u;
+    // the walking kernels unwind finished paths in batches, before a refill
+    constexpr bool kDeferUnwind = kRefillMin > 1u;
+    constexpr int kUnwindPending = 1 << 24;
     // a tree in LDS has at most 2048 records: its bounce stack entries take two bytes, known here
     const uint32_t bounce_bytes = NODES_IN_LDS || FILTER == kFilterShort ? 2u : a.stack_entry_bytes;
     WorkCount work = {};
@@ -299,6 +304,64 @@ trace_kernel(const TraceArgs a)
     bool w_pending = false;
     bool waited_last = false; // wave-uniform: the hit rays of the last pass were made to wait
 
+    // Unwinds the recursion of this lane's finished path -- per level, bytes -> float -> bytes (:569-578,
+    // :587-591) -- and adds the sample to its pixel (FinalColor += ray_color, :633-635).  Black stays black
+    // at every level (ToRGB of Color * 0, or of NaN for a non-finite Color, is 0), so the paths that ran
+    // out of depth -- the longest stacks -- have nothing to unwind.
+    auto unwind_and_add = [&](int cr, int cg, int cb) {
+        for (int l = (cr | cg | cb) != 0 ? level - 1 : -1; l >= 0; --l) {
+            const rt_sphere *sp = a.spheres + read_bounce(stack, bounce_bytes, l * kTraceThreads + tid);
+            RT_TALLY(wc, kSecReplayLevel);
+            if (sp->material == RT_MAT_DIFFUSE) {
+                cr >>= 1; cg >>= 1; cb >>= 1;
+            }
+            cr = to_byte(sp->color[0] * (float)cr);
+            cg = to_byte(sp->color[1] * (float)cg);
+            cb = to_byte(sp->color[2] * (float)cb);
+        }
+        const ConstArgs kt = fresh_args();
+        if (kt->direct_add) {
+            uint32_t *dst = kt->sums + (size_t)pixel * 3u;
+            atomicAdd(dst + 0, (uint32_t)cr);
+            atomicAdd(dst + 1, (uint32_t)cg);
+            atomicAdd(dst + 2, (uint32_t)cb);
+        } else {
+            atomicAdd(acc + acc_at + 0u, (uint32_t)cr | ((uint32_t)cg << 16));
+            atomicAdd(acc + acc_at + 1u, (uint32_t)cb);
+        }
+    };
+    // The paths of the lanes in `term` have added their samples: count them off their chunks, and add
+    // the sums of a chunk whose last path this was to the frame.
+    auto retire = [&](unsigned long long term) {
+        if (term != 0ull) {
+            const unsigned long long term1 = term & wave_ballot(acc_at >= 128u);
+            s_done1 += (uint32_t)__popcll(term1);
+            s_done0 += (uint32_t)__popcll(term & ~term1);
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const uint32_t total = sl ? s_total1 : s_total0, done = sl ? s_done1 : s_done0;
+                if (total != 0u && done == total) {
+                    if (lane < s_npx[sl]) {
+                        const ConstArgs ka = fresh_args();
+                        const int ly = lane / s_tw[sl], lx = lane - ly * s_tw[sl];
+                        uint32_t *dst = ka->sums + ((size_t)(s_x0[sl] + lx) + (size_t)(s_y0[sl] + ly) * ka->width) * 3u;
+                        uint32_t *src = acc + sl * 128 + lane * 2;
+                        const uint32_t sum[3] = { src[0] & 0xffffu, src[0] >> 16, src[1] };
+                        src[0] = src[1] = 0u;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            if (a.segments > 1u)
+                                atomicAdd(dst + ch, sum[ch]);
+                            else
+                                dst[ch] += sum[ch];
+                        }
+                    }
+                    if (sl) s_total1 = 0u; else s_total0 = 0u;
+                }
+            }
+        }
+    };
+
     unsigned long long idle_lanes = ~0ull; // the lanes without a path (= !active), kept as a lane mask too
     for (;;) {
         // ---- refill idle lanes from the wave's chunk, pulling new chunks as needed
@@ -309,6 +372,19 @@ trace_kernel(const TraceArgs a)
         // with some lanes empty costs less than refilling every pass.  Which pass a path starts in
         // does not enter its arithmetic.
         const bool refill_now = (uint32_t)__popcll(need) >= kRefillMin;
+        if (kDeferUnwind) {
+            // the paths that ended since the last refill unwind together: the loop runs to the deepest of
+            // them once, instead of to the deepest of every pass's few
+            const unsigned long long pend = wave_ballot(!active && (depth & kUnwindPending) != 0);
+            if (pend != 0ull && (refill_now || queue_empty)) {
+                if (__builtin_amdgcn_inverse_ballot_w64(pend)) {
+                    const int packed = depth;
+                    depth = 0;
+                    unwind_and_add(packed & 255, (packed >> 8) & 255, (packed >> 16) & 255);
+                }
+                retire(pend);
+            }
+        }
         while (need != 0ull && !queue_empty && refill_now) {
             if (w_next >= w_end) {
                 const ConstArgs kq = fresh_args(); // the call's shape is needed once per chunk: not worth registers
@@ -558,6 +634,7 @@ trace_kernel(const TraceArgs a)
         RT_CLOCK(wc, kTimePoints, t_mark);
         // ---- GetRayColor's branches, Source/main.cpp:562-597
         bool terminated = false;
+        bool deferred = false; // terminated, unwind still to come
         if (shade) {
             ++n_rays;
             RT_TALLY(wc, kSecShade);
@@ -674,29 +751,13 @@ trace_kernel(const TraceArgs a)
                 }
                 active = false;
             } else if (terminated) {
-                // unwind the recursion: per level, bytes -> float -> bytes (:569-578, :587-591).  Black
-                // stays black at every level (ToRGB of Color * 0, or of NaN for a non-finite Color, is 0),
-                // so the paths that ran out of depth -- the longest stacks -- have nothing to unwind.
-                for (int l = (cr | cg | cb) != 0 ? level - 1 : -1; l >= 0; --l) {
-                    const rt_sphere *sp = a.spheres + read_bounce(stack, bounce_bytes, l * kTraceThreads + tid);
-                    RT_TALLY(wc, kSecReplayLevel);
-                    if (sp->material == RT_MAT_DIFFUSE) {
-                        cr >>= 1; cg >>= 1; cb >>= 1;
-                    }
-                    cr = to_byte(sp->color[0] * (float)cr);
-                    cg = to_byte(sp->color[1] * (float)cg);
-                    cb = to_byte(sp->color[2] * (float)cb);
-                }
-                // FinalColor += ray_color, :633-635
-                const ConstArgs kt = fresh_args();
-                if (kt->direct_add) {
-                    uint32_t *dst = kt->sums + (size_t)pixel * 3u;
-                    atomicAdd(dst + 0, (uint32_t)cr);
-                    atomicAdd(dst + 1, (uint32_t)cg);
-                    atomicAdd(dst + 2, (uint32_t)cb);
+                if (kDeferUnwind) {
+                    // the unwind waits for the wave's next refill, with the other paths that end until then
+                    // (bytes of the colour in the path's depth counter, which has no other use from here on)
+                    depth = kUnwindPending | cr | (cg << 8) | (cb << 16);
+                    deferred = true;
                 } else {
-                    atomicAdd(acc + acc_at + 0u, (uint32_t)cr | ((uint32_t)cg << 16));
-                    atomicAdd(acc + acc_at + 1u, (uint32_t)cb);
+                    unwind_and_add(cr, cg, cb);
                 }
                 active = false;
             }
@@ -706,33 +767,7 @@ trace_kernel(const TraceArgs a)
         // ---- chunks whose last path has just terminated: add their sums to the frame
         const unsigned long long term = wave_ballot(terminated);
         idle_lanes |= term;
-        if (term != 0ull) {
-            const unsigned long long term1 = term & wave_ballot(acc_at >= 128u);
-            s_done1 += (uint32_t)__popcll(term1);
-            s_done0 += (uint32_t)__popcll(term & ~term1);
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
-                const uint32_t total = sl ? s_total1 : s_total0, done = sl ? s_done1 : s_done0;
-                if (total != 0u && done == total) {
-                    if (lane < s_npx[sl]) {
-                        const ConstArgs ka = fresh_args();
-                        const int ly = lane / s_tw[sl], lx = lane - ly * s_tw[sl];
-                        uint32_t *dst = ka->sums + ((size_t)(s_x0[sl] + lx) + (size_t)(s_y0[sl] + ly) * ka->width) * 3u;
-                        uint32_t *src = acc + sl * 128 + lane * 2;
-                        const uint32_t sum[3] = { src[0] & 0xffffu, src[0] >> 16, src[1] };
-                        src[0] = src[1] = 0u;
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) {
-                            if (a.segments > 1u)
-                                atomicAdd(dst + ch, sum[ch]);
-                            else
-                                dst[ch] += sum[ch];
-                        }
-                    }
-                    if (sl) s_total1 = 0u; else s_total0 = 0u;
-                }
-            }
-        }
+        retire(kDeferUnwind ? term & ~wave_ballot(deferred) : term);
         RT_CLOCK(wc, kTimeFlush, t_mark);
     }
 
