@@ -34,12 +34,16 @@
 #include "rt_list_scan.h"
 
 // Scheduling thresholds of the path kernel (lanes of a wave; overridable for sweeps): idle lanes before the
-// walking kernels refill, hit rays before they are shaded, idle lanes before the list scans refill.
+// walking kernels refill, hit rays before they are shaded (hierarchy in LDS; short lists, where 41 means
+// whenever the next pass refills), idle lanes before the list scans refill.
 #ifndef RT_REFILL_MIN_WALK
 #define RT_REFILL_MIN_WALK 24u
 #endif
 #ifndef RT_SHADE_MIN_WALK
 #define RT_SHADE_MIN_WALK 32u
+#endif
+#ifndef RT_SHADE_MIN_SHORT
+#define RT_SHADE_MIN_SHORT 41u
 #endif
 #ifndef RT_REFILL_MIN_LIST
 #define RT_REFILL_MIN_LIST 1u
@@ -213,9 +217,10 @@ trace_kernel(const TraceArgs a)
     constexpr uint32_t kRefillMin = FILTER == kFilterBvh || FILTER == kFilterShort ? RT_REFILL_MIN_WALK : RT_REFILL_MIN_LIST;
     // (a tree walked in memory makes the pass too dear for rays to sit one out: measured no gain)
     constexpr uint32_t kShadeMin = NODES_IN_LDS ? RT_SHADE_MIN_WALK : 0u;
+    constexpr uint32_t kShortShadeMin = RT_SHADE_MIN_SHORT;
     // the walking kernels unwind finished paths in batches, before a refill
     constexpr bool kDeferUnwind = kRefillMin > 1u;
-    constexpr int kUnwindPending = 1 << 24;
+    constexpr int kUnwindPending = 1 << 24; // (max_depth is at most 4096)
     // a tree in LDS has at most 2048 records: its bounce stack entries take two bytes, known here
     const uint32_t bounce_bytes = NODES_IN_LDS || FILTER == kFilterShort ? 2u : a.stack_entry_bytes;
     WorkCount work = {};
@@ -579,7 +584,7 @@ trace_kernel(const TraceArgs a)
                 }
             }
         }
-        if (FILTER == kFilterShort && active) {
+        if (FILTER == kFilterShort && active && !w_pending) {
             // the same records for every lane, never written while a kernel runs: scalar loads
             typedef const __attribute__((address_space(4))) float *ConstFloats;
             const ConstFloats eg = (ConstFloats)a.exact;
@@ -598,6 +603,27 @@ trace_kernel(const TraceArgs a)
                             best = (int)(i0 + j);
                     }
                 }
+            }
+        }
+        if (FILTER == kFilterShort && kShortShadeMin != 0u) {
+            // the same wait as in the hierarchy kernel; here only refilled lanes can join, so rays wait
+            // only when the next pass will refill
+            if (active && w_pending) {
+                closest = w_closest;
+                best = w_best;
+                w_pending = false;
+            }
+            const uint32_t n_hit = (uint32_t)__popcll(wave_ballot(active && best >= 0));
+            if (n_hit != 0u && n_hit < kShortShadeMin && !waited_last && !queue_empty && 64u - n_hit >= kRefillMin) {
+                if (active && best >= 0) {
+                    shade = false;
+                    w_pending = true;
+                    w_closest = closest;
+                    w_best = best;
+                }
+                waited_last = true;
+            } else {
+                waited_last = false;
             }
         }
         for (uint32_t t0 = 0u; FILTER != kFilterBvh && FILTER != kFilterShort && t0 < (MULTI_TILE ? a.n : 1u); t0 += a.tile_cap) {
