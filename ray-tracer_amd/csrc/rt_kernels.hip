@@ -7,6 +7,10 @@
 //     finished lanes from an 8x8-pixel chunk of (pixel, sample) items it pulls
 //     from a global queue (ballot + mbcnt ranks, no per-lane atomics), so waves
 //     never idle on short paths while long ones finish;
+//   * a section of the kernel costs a wave the same for one lane as for 64, so where a pass is cheap
+//     (hierarchy walk, short lists) lanes wait for company: idle lanes for a refill of 24 or more,
+//     rays with a hit for 32 ready to be shaded, finished paths for a common unwind before a refill.
+//     None of it enters a path's arithmetic;
 //   * a ray finds the spheres that need the reference's exact root evaluation through a
 //     CONSERVATIVE first phase, which may pass a sphere the reference rejects but never the
 //     reverse; whatever it passes is then resolved with the reference's exact, unfused
