@@ -38,8 +38,9 @@
 #include "rt_list_scan.h"
 
 // Scheduling thresholds of the path kernel (lanes of a wave; overridable for sweeps): idle lanes before the
-// walking kernels refill, hit rays before they are shaded (hierarchy in LDS; short lists, where 41 means
-// whenever the next pass refills), idle lanes before the list scans refill.
+// walking kernels refill (_MEM: hierarchy walked in memory), hit rays before they are shaded (hierarchy in
+// LDS, in memory; short lists, where 41 means whenever the next pass refills), idle lanes before the list
+// scans refill.
 #ifndef RT_REFILL_MIN_WALK
 #define RT_REFILL_MIN_WALK 24u
 #endif
@@ -48,6 +49,12 @@
 #endif
 #ifndef RT_SHADE_MIN_SHORT
 #define RT_SHADE_MIN_SHORT 41u
+#endif
+#ifndef RT_REFILL_MIN_MEM
+#define RT_REFILL_MIN_MEM 32u
+#endif
+#ifndef RT_SHADE_MIN_MEM
+#define RT_SHADE_MIN_MEM 20u
 #endif
 #ifndef RT_REFILL_MIN_LIST
 #define RT_REFILL_MIN_LIST 1u
@@ -218,9 +225,9 @@ trace_kernel(const TraceArgs a)
     constexpr bool MULTI_TILE = SPLIT && FILTER != kFilterBvh;
     constexpr bool NODES_IN_LDS = !SPLIT && FILTER == kFilterBvh;
     // (a pass of the list scans costs as much with one lane as with 64: they refill every idle lane at once)
-    constexpr uint32_t kRefillMin = FILTER == kFilterBvh || FILTER == kFilterShort ? RT_REFILL_MIN_WALK : RT_REFILL_MIN_LIST;
-    // (a tree walked in memory makes the pass too dear for rays to sit one out: measured no gain)
-    constexpr uint32_t kShadeMin = NODES_IN_LDS ? RT_SHADE_MIN_WALK : 0u;
+    constexpr uint32_t kRefillMin = FILTER == kFilterBvh || FILTER == kFilterShort ? (SPLIT ? RT_REFILL_MIN_MEM : RT_REFILL_MIN_WALK) : RT_REFILL_MIN_LIST;
+    // (a tree walked in memory makes the pass dearer: fewer rays wait, and a percent is all it gives)
+    constexpr uint32_t kShadeMin = NODES_IN_LDS ? RT_SHADE_MIN_WALK : (FILTER == kFilterBvh ? RT_SHADE_MIN_MEM : 0u);
     constexpr uint32_t kShortShadeMin = RT_SHADE_MIN_SHORT;
     // the walking kernels unwind finished paths in batches, before a refill
     constexpr bool kDeferUnwind = kRefillMin > 1u;
