@@ -183,7 +183,7 @@ def main():
     ctx.set_option(rtamd.OPT_FILTER, SCANS[args.scan])
     scan = args.scan
     if scan == "auto":  # the library's rule (rt_mi355x.h, RT_OPT_FILTER)
-        scan = "hierarchy" if N_SPHERES >= 64 else "vector"
+        scan = "hierarchy" if N_SPHERES >= 13 else "vector"
     cam = rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA)
     total_spp = SPP * world if args.scaling == "weak" else SPP
     p = dist_render.rank_params(W, H, total_spp, DEPTH, 1, args.partition, rank, world)

@@ -284,13 +284,13 @@ typedef enum rt_option {
      * for every sphere; 3 a per-ray walk of a bounding-box hierarchy built over the list
      * (the reference has none: it tests every sphere, Source/main.cpp:534), whose boxes are
      * padded so that no sphere the reference accepts is skipped; -1 (default) automatic:
-     * 3 from RT_OPT_BVH_MIN_SPHERES spheres up, else 2, or 1 below 96 spheres.  All give
+     * 3 from RT_OPT_BVH_MIN_SPHERES spheres up (13), else 2, or 1 below 96 spheres.  All give
      * bit-identical results; forcing one exists to prove it. */
     RT_OPT_FILTER = 0,
     RT_OPT_TILE_SPHERES = 1,      /* spheres per LDS tile, 128..4096 (default 512) */
     RT_OPT_WORKGROUPS_PER_CU = 2, /* cap on resident workgroups per CU, 0 = occupancy limit */
     RT_OPT_BVH_LEAF_SPHERES = 3,  /* most spheres per leaf of the hierarchy, 1..15 (default: 4, or 8 for trees too large for LDS) */
-    RT_OPT_BVH_MIN_SPHERES = 4,   /* scene size from which the automatic choice is the hierarchy */
+    RT_OPT_BVH_MIN_SPHERES = 4,   /* scene size from which the automatic choice is the hierarchy (default 13) */
     RT_OPT_BVH_LDS_NODES = 5,     /* hierarchies of up to this many nodes (and at most 2048 sphere records) are walked
                                      in LDS, 0..2048 (default 512) */
     RT_OPT_BVH_SUSPEND_LANES = 6, /* a 64-lane wave stops walking the hierarchy when at most this many of its rays

@@ -53,7 +53,8 @@ struct rt_context {
     uint32_t chunks_per_wave = 32; // work queue: split tiles' samples until there are this many chunks per resident wave
     uint32_t direct_add_samples = 1; // RT_OPT_DIRECT_ADD_SAMPLES
     bool count_work = false;       // RT_OPT_COUNT_WORK: launch the counting build of the trace kernel
-    uint32_t bvh_auto_min = 64;    // automatic choice: hierarchy from this many spheres up (measured crossover)
+    uint32_t bvh_auto_min = 13;    // automatic choice: hierarchy from this many spheres up (measured: it beats the
+                                   // vector scan from 16 spheres; lists of up to 12 have a kernel of their own)
     float4 *d_bvh_nodes = nullptr;
     Geom *d_bvh_geom = nullptr;
     uint32_t *d_bvh_index = nullptr;

@@ -16,7 +16,7 @@
 //     reverse; whatever it passes is then resolved with the reference's exact, unfused
 //     arithmetic and root selection, so results are bit-identical whichever phase 1 runs:
 //       - a walk over a bounding-box hierarchy built on the host (boxes padded per ray by the
-//         reference's own rounding slack; rt_bvh_walk.h), the default from 64 spheres up;
+//         reference's own rounding slack; rt_bvh_walk.h), the default from 13 spheres up;
 //       - the whole list, streamed through LDS tiles of {cx, cy, cz, r*r}, with a widened
 //         discriminant test on the FP32 matrix cores or with fused
 //         multiply-adds on the vector ALU (rt_list_scan.h), collecting one bit per test;
