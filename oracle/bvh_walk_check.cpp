@@ -132,7 +132,7 @@ extern "C" int orc_bvh_intersect(const rt_sphere *spheres, uint32_t n, int leaf_
         r.four_a = 4.0f * A;
         r.two_a = 2.0f * A;
         const float m = ((fabsf(r.ox) + fabsf(r.oy)) + (fabsf(r.oz) + fabsf(r.dx))) + (fabsf(r.dy) + fabsf(r.dz));
-        r.tame = (m < 0x1p28f) && (A >= 0x1p-40f);
+        r.tame = (m < 0x1p28f) && (A >= 0x1p-30f);
         if (!r.tame) {
             index[i] = -2;
             if (t) t[i] = 0.0f;

@@ -153,20 +153,70 @@ __device__ __forceinline__ void sky_float(float dy, float &r, float &g, float &b
 struct RayState {
     float ox, oy, oz, dx, dy, dz;
     float four_a, two_a; // 4*dot(D,D), 2*dot(D,D)
+    float a, inv_a;      // dot(D,D) and, for a tame ray, its correctly rounded reciprocal (see tame_root)
     float a_filter;      // dot(D,D) * (1 - 2^-17), the conservative filter's A
     bool tame;           // all components finite and small enough for the filter's bound
 };
 
 // Magnitude limits under which the conservative filter's arithmetic can neither
-// overflow nor lose its margin to underflow (see filter_sign).
+// overflow nor lose its margin to underflow (see filter_sign), and under which the halved form of
+// the root evaluation (tame_root) rounds like the reference's.
 constexpr float kTameMax = 0x1p28f;   // |coordinate|, |direction component|
-constexpr float kTameMinA = 0x1p-40f; // dot(D,D)
+constexpr float kTameMinA = 0x1p-30f; // dot(D,D)
+
+// ---------------------------------------------------------------------------
+// Correctly rounded division and square root in a few instructions
+// ---------------------------------------------------------------------------
+//
+// The reference divides and takes square roots with x86-64's divss and sqrtss: IEEE-754, rounded to
+// nearest.  The compiler's expansions of `/` and sqrtf give the same results in 12 and 18 instructions
+// (range scaling, a refined reciprocal per division, special-case fix-ups).  The sequences below give
+// the same results in 3 and 5 for operands inside the stated ranges -- not by an error analysis but by
+// enumeration on the MI355X itself (tools/exact_arith.hip): every float of the range for the
+// reciprocal and the square root, all 2^46 pairs of significands for the quotient (scaling an operand
+// by a power of two scales every intermediate exactly, and the sequences are odd in their operands).
+// Outside the ranges the callers use `/` and sqrtf.
+
+// 1 / x, correctly rounded, for 2^-100 <= |x| < 2^126: one correction of the hardware's approximation.
+__device__ __forceinline__ float exact_rcp(float x)
+{
+    const float y0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+
+// a / b, correctly rounded, from y = exact_rcp(b): the product is within an ulp or two of the
+// quotient, the residual a - b q is exact in one fused multiply-add and a second one rounds q + r y
+// to the float nearest a / b.  Needs b, y, the quotient and the residual (about 2^-24 |a|) in the
+// normal range.
+__device__ __forceinline__ float exact_div(float a, float b, float y)
+{
+    const float q = a * y;
+    const float r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+
+// sqrt(x), correctly rounded, for x >= 0: from 2^-100 up, one correction of the hardware's
+// approximation by its residual and half the approximate reciprocal root; below (zero, subnormals,
+// where those approximations are not good enough), sqrtf -- taken by the whole wave as soon as one
+// of its lanes needs it.
+__device__ __forceinline__ float exact_sqrt(float x)
+{
+    if (wave_any(x < 0x1p-100f))
+        return sqrtf(x);
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+    const float r = __builtin_fmaf(-s0, s0, x);
+    return __builtin_fmaf(r, h, s0);
+}
 
 __device__ __forceinline__ void ray_prepare(RayState &r)
 {
     const float A = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz; // dot(): products summed left to right
     r.four_a = 4.0f * A;
     r.two_a = 2.0f * A;
+    r.a = A;
+    r.inv_a = exact_rcp(A); // (meaningless for an untame ray, and never used for one)
     r.a_filter = __builtin_fmaf(-0x1p-17f, A, A);
     // the sum of magnitudes is NaN or Inf as soon as one component is, and comparisons with NaN
     // are false: one test covers "finite" and "small enough" (it is a little stricter than a test
@@ -265,13 +315,75 @@ __device__ __forceinline__ void resolve_unordered(const RayState &r, const Geom 
     }
 }
 
-// Hit point and normal, Source/main.cpp:503-514.
+// The same for a tame ray (finite, magnitudes below 2^28, A = dot(D,D) at least 2^-30), with every
+// quantity at half or a quarter of the reference's: d = B / 2, disc = Discriminant / 4, and roots
+// (-d -+ sqrt(disc)) / A.  Scaling by a power of two commutes with every rounding as long as nothing
+// leaves the normal range, so each value is the reference's, scaled, and the root is the reference's,
+// bit for bit.  Where something does leave the normal range the root is below tmin on both sides: a
+// root of at least tmin = 0.001 needs |d| or sqrt(disc) of at least 2^-41 (A >= 2^-30), so the
+// larger of d*d and disc is at least 2^-82, and a product below 2^-126 next to it is lost in the
+// reference's rounding of the difference as well.  (The early-out `disc < 0` can differ from the
+// reference's only when both products are subnormal, i.e. when no root reaches tmin.)
+__device__ __forceinline__ float tame_discriminant(const RayState &r, const Geom &s, float &d, float &C)
+{
+    const float ocx = r.ox - s.cx, ocy = r.oy - s.cy, ocz = r.oz - s.cz;
+    d = ocx * r.dx + ocy * r.dy + ocz * r.dz;
+    C = (ocx * ocx + ocy * ocy + ocz * ocz) - s.r2;
+    return d * d - r.a * C;
+}
+
+// Effective root (Source/main.cpp:490-499) for a tame ray without NaNs: the near root if it is >=
+// tmin, else the far root; both are formed (three instructions each) rather than branched on.
+__device__ __forceinline__ float tame_root(const RayState &r, float d, float disc, float tmin)
+{
+    const float sq = exact_sqrt(disc);
+    const float near_root = exact_div(-d - sq, r.a, r.inv_a);
+    const float far_root = exact_div(sq - d, r.a, r.inv_a);
+    return near_root < tmin ? far_root : near_root;
+}
+
+// resolve_unordered for a tame ray.
+__device__ __forceinline__ void resolve_unordered_tame(const RayState &r, const Geom &s, int idx, float tmin,
+                                                       float &closest, int &best, WorkCount *wc = nullptr)
+{
+    float d, C;
+    const float disc = tame_discriminant(r, s, d, C);
+    if (wc)
+        ++wc->exact;
+    if (disc < 0.0f)
+        return;
+    if (wc)
+        ++wc->roots;
+    const float root = tame_root(r, d, disc, tmin);
+    if (root >= tmin && (root < closest || (root == closest && idx > best))) {
+        closest = root;
+        best = idx;
+    }
+}
+
+// Hit point and normal, Source/main.cpp:503-514.  TAME_SCENE: every radius of the scene has a
+// magnitude in [2^-20, 2^28) (the precondition of every scan but the exact one); then the three
+// divisions by the radius go through its reciprocal whenever all three numerators of all the wave's
+// rays have magnitudes in [2^-80, 2^80] (zero, subnormal, huge or NaN ones send the wave to `/`).
+template <bool TAME_SCENE = false>
 __device__ __forceinline__ void hit_frame(const RayState &r, float t, float cx, float cy, float cz,
                                           float radius, float &px, float &py, float &pz, float &nx,
                                           float &ny, float &nz, bool &inside)
 {
     px = r.ox + (r.dx * t); py = r.oy + (r.dy * t); pz = r.oz + (r.dz * t);
-    nx = (px - cx) / radius; ny = (py - cy) / radius; nz = (pz - cz) / radius;
+    const float x0 = px - cx, x1 = py - cy, x2 = pz - cz;
+    bool slow = true;
+    if (TAME_SCENE) {
+        const float lo = fminf(fminf(fabsf(x0), fabsf(x1)), fabsf(x2));
+        const float hi = fmaxf(fmaxf(fabsf(x0), fabsf(x1)), fabsf(x2));
+        slow = wave_any(!(lo >= 0x1p-80f && hi <= 0x1p80f));
+    }
+    if (slow) {
+        nx = x0 / radius; ny = x1 / radius; nz = x2 / radius;
+    } else {
+        const float inv = exact_rcp(radius);
+        nx = exact_div(x0, radius, inv); ny = exact_div(x1, radius, inv); nz = exact_div(x2, radius, inv);
+    }
     inside = (r.dx * nx + r.dy * ny + r.dz * nz) > 0.0f;
     if (inside) {
         nx = -nx; ny = -ny; nz = -nz;

@@ -13,25 +13,20 @@ namespace {
 // with B > 0 and C > 0 (origin outside, centre behind) is dropped without a square root: then
 // 4AC > 0, so fl(B*B - 4AC) <= fl(B*B), its correctly rounded root is at most sqrt(fl(B*B)) = |B|,
 // both numerators -B -+ sq are <= 0 and the reference rejects both roots against tmin > 0.
-__device__ __forceinline__ bool leaf_candidate(const RayState &r, const Geom &s, float &B, float &disc)
+// Only tame rays walk the tree: B is kept as d = B / 2 and the discriminant at a quarter (tame_root).
+__device__ __forceinline__ bool leaf_candidate(const RayState &r, const Geom &s, float &d, float &disc)
 {
-    const float ocx = r.ox - s.cx, ocy = r.oy - s.cy, ocz = r.oz - s.cz;
-    const float d = ocx * r.dx + ocy * r.dy + ocz * r.dz;
-    B = d + d;
-    const float C = (ocx * ocx + ocy * ocy + ocz * ocz) - s.r2;
-    disc = B * B - r.four_a * C;
-    return !(disc < 0.0f) && !(B > 0.0f && C > 0.0f);
+    float C;
+    disc = tame_discriminant(r, s, d, C);
+    return !(disc < 0.0f) && !(d > 0.0f && C > 0.0f);
 }
 
 // Second half: the effective root (Source/main.cpp:490-499) and the closest-hit update; the
 // list index is fetched only when the root is in range.
-__device__ __forceinline__ void leaf_root(const RayState &r, float B, float disc, const uint32_t *index, float tmin,
+__device__ __forceinline__ void leaf_root(const RayState &r, float d, float disc, const uint32_t *index, float tmin,
                                           float &closest, int &best)
 {
-    const float sq = sqrtf(disc);
-    float root = (-B - sq) / r.two_a;
-    if (root < tmin)
-        root = (-B + sq) / r.two_a;
+    const float root = tame_root(r, d, disc, tmin);
     if (root >= tmin && root <= closest) {
         const int idx = (int)*index;
         if (root < closest || idx > best) {
@@ -140,7 +135,7 @@ __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, f
     for (uint32_t i = 0; i < b.n_large; ++i) {
         Geom g;
         g.cx = lg[4u * i + 0u]; g.cy = lg[4u * i + 1u]; g.cz = lg[4u * i + 2u]; g.r2 = lg[4u * i + 3u];
-        resolve_unordered(r, g, (int)li[i], tmin, closest, best, wc);
+        resolve_unordered_tame(r, g, (int)li[i], tmin, closest, best, wc);
     }
     node = b.n_nodes ? 0 : kBvhDone;
     sp = 0u;

@@ -555,7 +555,11 @@ trace_kernel(const TraceArgs a)
                     w_closest = INFINITY;
                     w_best = -1;
                     w_node = kBvhDone;
-                    scan_tile<kFilterExact>(a.exact, a.exact, a.n, 0u, ray, 0.001f, w_closest, w_best, wc);
+                    // (its per-ray factors are formed here, for the rare ray that needs them, rather than
+                    // carried in registers by every ray)
+                    RayState plain = ray;
+                    ray_prepare(plain);
+                    scan_tile<kFilterExact>(a.exact, a.exact, a.n, 0u, plain, 0.001f, w_closest, w_best, wc);
                 }
             }
             if (wave_active) {
@@ -648,8 +652,11 @@ trace_kernel(const TraceArgs a)
                 if (wave_active)
                     scan_tile_matrix(reinterpret_cast<const float *>(tile_f), a.exact + t0, round_up_group(cnt), t0, mo,
                                      ray, mine, lane, 0.001f, closest, best, wc);
-                if (active && !ray.tame) // NaN, Inf, zero or huge rays: the reference's in-order loop
-                    scan_tile<kFilterExact>(a.exact + t0, a.exact + t0, cnt, t0, ray, 0.001f, closest, best, wc);
+                if (active && !ray.tame) { // NaN, Inf, zero or huge rays: the reference's in-order loop
+                    RayState plain = ray;
+                    ray_prepare(plain);
+                    scan_tile<kFilterExact>(a.exact + t0, a.exact + t0, cnt, t0, plain, 0.001f, closest, best, wc);
+                }
             } else if (active) {
                 scan_tile<FILTER>(tile_f, tile_e, cnt, t0, ray, 0.001f, closest, best, wc);
             }
@@ -692,8 +699,8 @@ trace_kernel(const TraceArgs a)
                     // glm::refract (func_geometric.inl:110-127) on the normalised direction.
                     float px, py, pz, nx, ny, nz;
                     bool inside;
-                    hit_frame(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius,
-                              px, py, pz, nx, ny, nz, inside);
+                    hit_frame<FILTER != kFilterExact>(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius,
+                                                      px, py, pz, nx, ny, nz, inside);
                     const float inv = 1.0f / sqrtf(ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz);
                     const float ux = ray.dx * inv, uy = ray.dy * inv, uz = ray.dz * inv;
                     const float ratio = inside ? 1.5f : (1.0f / 1.5f);
@@ -734,8 +741,8 @@ trace_kernel(const TraceArgs a)
                     float px, py, pz, nx, ny, nz;
                     bool inside;
                     RT_TALLY(wc, kSecScatter);
-                    hit_frame(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius,
-                              px, py, pz, nx, ny, nz, inside);
+                    hit_frame<FILTER != kFilterExact>(ray, closest, sp->center[0], sp->center[1], sp->center[2], sp->radius,
+                                                      px, py, pz, nx, ny, nz, inside);
                     float ndx, ndy, ndz;
                     if (material == RT_MAT_DIFFUSE) {
                         // S = Normal + GeneratePointInUnitSphere(), :566

@@ -225,7 +225,7 @@ __device__ __forceinline__ void scan_tile_matrix(const float *__restrict__ filt,
                 const uint32_t rest = word & ~(0x80000000u >> pos);
                 if (j == 0) o0 = rest; else if (j == 1) o1 = rest; else if (j == 2) o2 = rest; else o3 = rest;
                 const uint32_t i = g0 + 16u * (uint32_t)(pos >> 2) + 4u * (uint32_t)((k + j) & 3) + (uint32_t)(pos & 3);
-                resolve_unordered(r, exact[i], (int)(base + i), tmin, closest, best, wc);
+                resolve_unordered_tame(r, exact[i], (int)(base + i), tmin, closest, best, wc); // (`mine` rays are tame)
             }
         }
     }
