@@ -342,6 +342,30 @@ __device__ __forceinline__ float tame_root(const RayState &r, float d, float dis
     return near_root < tmin ? far_root : near_root;
 }
 
+// resolve_candidate for a tame ray: the in-order rule (an equal T is accepted, so the later sphere
+// wins a tie), both roots formed rather than branched on.
+__device__ __forceinline__ bool resolve_candidate_tame(const RayState &r, const Geom &s, float tmin, float &closest,
+                                                       WorkCount *wc = nullptr)
+{
+    float d, C;
+    const float disc = tame_discriminant(r, s, d, C);
+    if (wc)
+        ++wc->exact;
+    if (disc < 0.0f)
+        return false;
+    if (wc)
+        ++wc->roots;
+    const float sq = exact_sqrt(disc);
+    const float near_root = exact_div(-d - sq, r.a, r.inv_a);
+    const float far_root = exact_div(sq - d, r.a, r.inv_a);
+    const bool near_out = near_root < tmin || near_root > closest;
+    const float root = near_out ? far_root : near_root;
+    if (root < tmin || root > closest)
+        return false;
+    closest = root;
+    return true;
+}
+
 // resolve_unordered for a tame ray.
 __device__ __forceinline__ void resolve_unordered_tame(const RayState &r, const Geom &s, int idx, float tmin,
                                                        float &closest, int &best, WorkCount *wc = nullptr)

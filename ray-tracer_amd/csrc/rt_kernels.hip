@@ -32,6 +32,8 @@
 // Build with -ffp-contract=off: every float multiply and add must round on its
 // own, as in the reference's x86-64 build; sqrt and divide are IEEE (hipcc's
 // default -fhip-fp32-correctly-rounded-divide-sqrt).
+#include <type_traits>
+
 #include "rt_arith.h"
 #include "rt_bvh_walk.h"
 #include "rt_device.h"
@@ -604,20 +606,32 @@ trace_kernel(const TraceArgs a)
             typedef const __attribute__((address_space(4))) float *ConstFloats;
             const ConstFloats eg = (ConstFloats)a.exact;
             // four records per round of loads (the array is padded far beyond the list's end)
-            for (uint32_t i0 = 0u; i0 < a.n; i0 += 4u) {
-                float rec[16];
+            auto in_order = [&](auto tame_rays, const RayState &rs) {
+                for (uint32_t i0 = 0u; i0 < a.n; i0 += 4u) {
+                    float rec[16];
 #pragma unroll
-                for (uint32_t q = 0u; q < 16u; ++q)
-                    rec[q] = eg[4u * i0 + q];
+                    for (uint32_t q = 0u; q < 16u; ++q)
+                        rec[q] = eg[4u * i0 + q];
 #pragma unroll
-                for (uint32_t j = 0u; j < 4u; ++j) {
-                    if (i0 + j < a.n) {
-                        Geom g;
-                        g.cx = rec[4u * j + 0u]; g.cy = rec[4u * j + 1u]; g.cz = rec[4u * j + 2u]; g.r2 = rec[4u * j + 3u];
-                        if (resolve_candidate(ray, g, 0.001f, closest, wc))
-                            best = (int)(i0 + j);
+                    for (uint32_t j = 0u; j < 4u; ++j) {
+                        if (i0 + j < a.n) {
+                            Geom g;
+                            g.cx = rec[4u * j + 0u]; g.cy = rec[4u * j + 1u]; g.cz = rec[4u * j + 2u]; g.r2 = rec[4u * j + 3u];
+                            if (decltype(tame_rays)::value ? resolve_candidate_tame(rs, g, 0.001f, closest, wc)
+                                                           : resolve_candidate(rs, g, 0.001f, closest, wc))
+                                best = (int)(i0 + j);
+                        }
                     }
                 }
+            };
+            // the short division and square root while every ray of the wave is tame, else (NaN, Inf,
+            // zero or huge rays in the wave) the compiler's, with the per-ray factors formed here
+            if (!wave_any(!ray.tame)) {
+                in_order(std::true_type(), ray);
+            } else {
+                RayState plain = ray;
+                ray_prepare(plain);
+                in_order(std::false_type(), plain);
             }
         }
         if (FILTER == kFilterShort && kShortShadeMin != 0u) {
