@@ -197,6 +197,26 @@ int rt_accumulate_device(rt_context *ctx, const rt_camera *cam, const rt_params 
                          int xstart, int ystart, int xsize, int ysize, uint32_t *d_sums,
                          void *stream);
 
+/* Several rt_accumulate_device calls in ONE launch.  TraceScene starts its four strips one after
+ * the other and never waits for any of them (Source/main.cpp:647-659), so the threads of one strip
+ * finish while the others still run; a launch of its own per strip (or per frame, per pass, per
+ * device share) would instead end with the device draining that call's last paths -- up to
+ * max_depth bounces with ever fewer lanes at work, about 0.2 ms -- before the next begins.  Here
+ * the jobs' work follows each other through one work queue: waves that find job k handed out go
+ * on with job k + 1 while job k's last paths still bounce.  Every job is what one
+ * rt_accumulate_device call takes (own camera, frame, sample range, tile set, region, d_sums) and
+ * its sums are exactly what that call would add.  The jobs must share params.seed and
+ * params.flags; two jobs may add into the same d_sums (same frame) or into buffers that do not
+ * overlap.  n_jobs <= RT_MAX_JOBS. */
+#define RT_MAX_JOBS 8
+typedef struct rt_job {
+    rt_camera cam;
+    rt_params params;
+    int32_t xstart, ystart, xsize, ysize;
+    uint32_t *d_sums;
+} rt_job;
+int rt_accumulate_batch_device(rt_context *ctx, const rt_job *jobs, uint32_t n_jobs, void *stream);
+
 /* FinalColor / SPP, ToRGB, PutPixel (Source/main.cpp:638-642) over the tile:
  * d_rgb = clamp(d_sums / spp_div, 0, 255); `flags` may carry RT_FLAG_GAMMA2. */
 int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, uint32_t height,
@@ -289,7 +309,8 @@ typedef enum rt_option {
     RT_OPT_FILTER = 0,
     RT_OPT_TILE_SPHERES = 1,      /* spheres per LDS tile, 128..4096 (default 512) */
     RT_OPT_WORKGROUPS_PER_CU = 2, /* cap on resident workgroups per CU, 0 = occupancy limit */
-    RT_OPT_BVH_LEAF_SPHERES = 3,  /* most spheres per leaf of the hierarchy, 1..15 (default: 4, or 8 for trees too large for LDS) */
+    RT_OPT_BVH_LEAF_SPHERES = 3,  /* most spheres per leaf of the hierarchy, 1..15, or 0 (default) = by scene size: 4, or 8 for
+                                     trees too large for LDS */
     RT_OPT_BVH_MIN_SPHERES = 4,   /* scene size from which the automatic choice is the hierarchy (default 13) */
     RT_OPT_BVH_LDS_NODES = 5,     /* hierarchies of up to this many nodes (and at most 2048 sphere records) are walked
                                      in LDS, 0..2048 (default 512) */
@@ -309,6 +330,8 @@ typedef enum rt_option {
 } rt_option;
 
 int rt_set_option(rt_context *ctx, int option, int64_t value);
+/* The option's current value as rt_set_option takes it (a fresh context reports the defaults). */
+int rt_get_option(rt_context *ctx, int option, int64_t *value);
 
 /* Builds the hierarchy of RT_OPT_FILTER 3 for `spheres` on the host and checks its structure
  * (every sphere in exactly one leaf or on the always-tested list, every box contains what is

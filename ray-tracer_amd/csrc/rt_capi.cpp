@@ -20,6 +20,7 @@
 
 using namespace rtamd;
 
+static_assert(kMaxJobs == RT_MAX_JOBS, "the kernels' job table and the header's limit");
 constexpr size_t kCounterBytes = (size_t)kCounterSlots * kCounterWords * sizeof(unsigned long long);
 
 // Geometry lists and LDS tiles are padded to whole candidate groups of the matrix scan.
@@ -335,20 +336,69 @@ int bvh_args(rt_context *ctx, BvhArgs &out, bool may_build = true)
     return RT_OK;
 }
 
-// Enqueues the sample loop for `region` into d_sums.  `queue_heads` = the work queue to use (null:
-// the context's own); with `may_allocate` false nothing is allocated on the way (the hierarchy
-// must be on the device already).
-int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p, const Region &rg,
-                       uint32_t *d_sums, hipStream_t stream, uint32_t *queue_heads = nullptr,
-                       bool may_allocate = true)
-{
-    if (rg.w == 0 || rg.h == 0)
-        return RT_OK;
-    if (p->max_depth <= 0) // GetRayColor(ray, 0) is RGB(0,0,0) (Source/main.cpp:555-558): nothing to add
-        return RT_OK;
+// One job of a trace launch as the entry points hand it over: already checked (check_params), region clipped.
+struct JobSpec {
+    const rt_camera *cam;
+    rt_params p;
+    Region rg;
+    uint32_t *d_sums;
+};
 
+// Enqueues ONE trace launch for `n` jobs (the sample loops of n frames, sample ranges or tile sets,
+// each into its own sums; same seed and flags).  `queue_heads` = the work queue to use (null: the
+// context's own); with `may_allocate` false nothing is allocated on the way (the hierarchy must be on
+// the device already).
+int enqueue_jobs(rt_context *ctx, const JobSpec *specs, uint32_t n, hipStream_t stream, uint32_t *queue_heads = nullptr,
+                 bool may_allocate = true)
+{
     TraceArgs a;
     memset(&a, 0, sizeof a);
+    // ---- the jobs that have something to trace
+    for (uint32_t i = 0; i < n; ++i) {
+        const JobSpec &js = specs[i];
+        if (js.rg.w == 0 || js.rg.h == 0)
+            continue;
+        if (js.p.max_depth <= 0) // GetRayColor(ray, 0) is RGB(0,0,0) (Source/main.cpp:555-558): nothing to add
+            continue;
+        TraceJob &j = a.jobs[a.n_jobs];
+        j.tiles_x = (uint32_t)(js.rg.w + kTileW - 1) / kTileW;
+        j.tiles_y = (uint32_t)(js.rg.h + kTileH - 1) / kTileH;
+        const uint32_t n_tiles = j.tiles_x * j.tiles_y;
+        j.tile_stride = js.p.tile_stride ? js.p.tile_stride : 1u;
+        j.tile_first = js.p.tile_first;
+        if (j.tile_stride == 1u && j.tile_first != 0u)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "tile_first without tile_stride");
+        if (j.tile_first >= j.tile_stride && j.tile_stride > 1u)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "tile_first must be below tile_stride");
+        j.n_chunks = j.tile_first < n_tiles ? (n_tiles - j.tile_first + j.tile_stride - 1u) / j.tile_stride : 0u;
+        if (j.n_chunks == 0u)
+            continue;
+        if (a.n_jobs == 0u) {
+            a.flags = js.p.flags;
+            a.key0 = (uint32_t)js.p.seed;
+            a.key1 = (uint32_t)(js.p.seed >> 32);
+        } else if (a.flags != js.p.flags || a.key0 != (uint32_t)js.p.seed || a.key1 != (uint32_t)(js.p.seed >> 32)) {
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "the jobs of one launch must share seed and flags");
+        }
+        j.cam = *js.cam;
+        j.width = js.p.width;
+        j.height = js.p.height;
+        j.width_d = (double)(float)js.p.width;
+        j.height_d = (double)(float)js.p.height;
+        j.inv_width = 1.0 / j.width_d;
+        j.inv_height = 1.0 / j.height_d;
+        j.sample_begin = js.p.sample_begin;
+        j.sample_count = js.p.sample_count ? js.p.sample_count : js.p.spp;
+        j.max_depth = js.p.max_depth;
+        j.x0 = js.rg.x0; j.y0 = js.rg.y0; j.w = js.rg.w; j.h = js.rg.h;
+        j.sums = js.d_sums;
+        a.max_depth = std::max(a.max_depth, j.max_depth);
+        ++a.n_jobs;
+    }
+    if (a.n_jobs == 0u)
+        return RT_OK;
+
+    // ---- what the jobs share: the scene, the scan, the kernel's shape
     a.filter = chosen_filter(ctx);
     if (a.filter == kFilterBvh) {
         const int st = bvh_args(ctx, a.bvh, may_allocate);
@@ -360,34 +410,7 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     memcpy(a.shift, ctx->shift, sizeof a.shift);
     a.spheres = ctx->d_spheres;
     a.n = ctx->n_spheres;
-    a.cam = *cam;
-    a.width = p->width;
-    a.height = p->height;
-    a.width_d = (double)(float)p->width;
-    a.height_d = (double)(float)p->height;
-    a.inv_width = 1.0 / a.width_d;
-    a.inv_height = 1.0 / a.height_d;
-    a.sample_begin = p->sample_begin;
-    a.sample_count = p->sample_count ? p->sample_count : p->spp;
-    a.max_depth = p->max_depth;
-    a.flags = p->flags;
     a.count_work = ctx->count_work ? 1u : 0u;
-    a.key0 = (uint32_t)p->seed;
-    a.key1 = (uint32_t)(p->seed >> 32);
-    a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
-    a.tiles_x = (uint32_t)(rg.w + kTileW - 1) / kTileW;
-    a.tiles_y = (uint32_t)(rg.h + kTileH - 1) / kTileH;
-    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
-    a.tile_stride = p->tile_stride ? p->tile_stride : 1u;
-    a.tile_first = p->tile_first;
-    if (a.tile_stride == 1u && a.tile_first != 0u)
-        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "tile_first without tile_stride");
-    if (a.tile_first >= a.tile_stride && a.tile_stride > 1u)
-        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "tile_first must be below tile_stride");
-    a.n_chunks = a.tile_first < n_tiles ? (n_tiles - a.tile_first + a.tile_stride - 1u) / a.tile_stride : 0u;
-    if (a.n_chunks == 0u)
-        return RT_OK;
-    a.sums = d_sums;
     a.rays = ctx->d_rays;
     a.chunk_counter = queue_heads ? queue_heads : ctx->d_chunk_counter;
 
@@ -427,46 +450,64 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     // every workgroup's 4 waves pull chunks until the queue is empty, so the grid
     // only needs to fill the chip
     uint32_t n_wg = (uint32_t)ctx->n_cus * (uint32_t)per_cu;
-    // A chunk is owned by one wave.  A call with few tiles per resident wave (a small frame, or
+
+    // ---- the work queue: every job's tiles cut into chunks
+    // A chunk is owned by one wave.  A job with few tiles per resident wave (a small frame, or
     // one rank's share of a frame) would leave waves idle or the last ones running alone, so its
     // tiles are cut into smaller chunks of at least 256 paths: first into 2 or 4 strips of rows
     // (disjoint pixels, plain stores), then the sample range into segments (atomic adds).
-    a.subtiles = 1u;
-    a.segments = 1u;
-    a.seg_samples = a.sample_count;
-    {
+    uint64_t total_chunks = 0u;
+    for (uint32_t i = 0; i < a.n_jobs; ++i) {
+        TraceJob &j = a.jobs[i];
+        j.subtiles = 1u;
+        j.segments = 1u;
+        j.seg_samples = j.sample_count;
+        // (the jobs of a launch follow each other through the queue: each is cut as if it were alone, so
+        // that the waves find the same granularity at every job's end)
         const uint64_t wanted = (uint64_t)ctx->chunks_per_wave * 4u * n_wg;
-        uint64_t per_tile = (wanted + a.n_chunks - 1u) / a.n_chunks; // chunks wanted of each tile
-        if (per_tile >= 2u && ctx->subtiles_max >= 2u && a.sample_count >= 8u)
-            a.subtiles = 2u;
-        if (per_tile >= 3u && ctx->subtiles_max >= 4u && a.sample_count >= 16u)
-            a.subtiles = 4u;
-        per_tile = (per_tile + a.subtiles - 1u) / a.subtiles;
-        const uint32_t min_segment = 4u * a.subtiles; // 256 paths on 64, 32 or 16 pixels
-        uint32_t per = a.sample_count;
-        if (per_tile >= 2u && a.sample_count >= 2u * min_segment) {
-            per = (uint32_t)((a.sample_count + per_tile - 1u) / per_tile);
+        uint64_t per_tile = (wanted + j.n_chunks - 1u) / j.n_chunks; // chunks wanted of each tile
+        if (per_tile >= 2u && ctx->subtiles_max >= 2u && j.sample_count >= 8u)
+            j.subtiles = 2u;
+        if (per_tile >= 3u && ctx->subtiles_max >= 4u && j.sample_count >= 16u)
+            j.subtiles = 4u;
+        per_tile = (per_tile + j.subtiles - 1u) / j.subtiles;
+        const uint32_t min_segment = 4u * j.subtiles; // 256 paths on 64, 32 or 16 pixels
+        uint32_t per = j.sample_count;
+        if (per_tile >= 2u && j.sample_count >= 2u * min_segment) {
+            per = (uint32_t)((j.sample_count + per_tile - 1u) / per_tile);
             if (per < min_segment)
                 per = min_segment;
         }
-        // a wave sums a chunk's samples of a pixel in 16 bits per channel: at most 257 samples of 255
+        // a wave sums a chunk's samples of a pixel in 16 bits per channel: at most 256 samples of 255
         if (per > kSegmentSamplesMax)
             per = kSegmentSamplesMax;
-        if (per < a.sample_count) {
-            a.segments = (a.sample_count + per - 1u) / per; // every segment non-empty
-            a.seg_samples = per;
+        if (per < j.sample_count) {
+            j.segments = (j.sample_count + per - 1u) / per; // every segment non-empty
+            j.seg_samples = per;
         }
-        uint64_t total = (uint64_t)a.n_chunks * a.subtiles * a.segments;
-        if (total > 0x7fffffffull && a.subtiles > 1u) {
-            a.subtiles = 1u;
-            total = (uint64_t)a.n_chunks * a.segments;
+        uint64_t total = (uint64_t)j.n_chunks * j.subtiles * j.segments;
+        if (total > 0x3fffffffull && j.subtiles > 1u) {
+            j.subtiles = 1u;
+            total = (uint64_t)j.n_chunks * j.segments;
         }
-        if (total > 0x7fffffffull)
-            return fail(ctx, RT_ERR_INVALID_ARGUMENT,
-                        "too many tiles x samples for one call's work queue: split the samples over several calls");
-        a.n_chunks = (uint32_t)total;
+        if (total_chunks + total > 0x7fffffffull)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "too many tiles x samples for one launch's work queue");
+        j.chunk_first = (uint32_t)total_chunks;
+        j.n_chunks = (uint32_t)total;
+        total_chunks += total;
+        // plain stores only where this launch has a single writer per pixel: samples in one segment, and no
+        // other job adding into the same memory
+        j.atomic_flush = j.segments > 1u ? 1u : 0u;
+        const uintptr_t lo = (uintptr_t)j.sums, hi = lo + (size_t)j.width * j.height * 3u * sizeof(uint32_t);
+        for (uint32_t o = 0; o < a.n_jobs; ++o) {
+            const TraceJob &other = a.jobs[o];
+            const uintptr_t olo = (uintptr_t)other.sums, ohi = olo + (size_t)other.width * other.height * 3u * sizeof(uint32_t);
+            if (o != i && lo < ohi && olo < hi)
+                j.atomic_flush = 1u;
+        }
     }
-    a.direct_add = a.seg_samples <= ctx->direct_add_samples ? 1u : 0u;
+    a.n_chunks = (uint32_t)total_chunks;
+    a.direct_add = (a.n_jobs == 1u && a.jobs[0].seg_samples <= ctx->direct_add_samples) ? 1u : 0u;
     const uint32_t by_chunks = (a.n_chunks + 3u) / 4u;
     if (n_wg > by_chunks)
         n_wg = by_chunks;
@@ -480,6 +521,31 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     RT_HIP(ctx, launch_trace(a, n_wg, stream));
     RT_HIP(ctx, hipEventRecord(ctx->ev_trace, stream));
     ctx->trace_enqueued = true;
+    return RT_OK;
+}
+
+// Enqueues the sample loop for `region` into d_sums: one job, or, where the job's tiles x sample
+// segments outnumber what one launch's work queue can count, its sample range in several launches.
+int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p, const Region &rg,
+                       uint32_t *d_sums, hipStream_t stream, uint32_t *queue_heads = nullptr,
+                       bool may_allocate = true)
+{
+    JobSpec js = { cam, *p, rg, d_sums };
+    const uint32_t first = p->sample_begin, count = p->sample_count ? p->sample_count : p->spp;
+    // at most 2^30 chunks per launch at the finest cut (256 samples per chunk of a whole tile)
+    const uint64_t tiles = (uint64_t)((rg.w + kTileW - 1) / kTileW) * (uint64_t)((rg.h + kTileH - 1) / kTileH);
+    const uint64_t segs = (count + kSegmentSamplesMax - 1u) / kSegmentSamplesMax;
+    if (tiles * segs <= 0x3fffffffull)
+        return enqueue_jobs(ctx, &js, 1u, stream, queue_heads, may_allocate);
+    const uint64_t segs_per_launch = std::max<uint64_t>(0x3fffffffull / std::max<uint64_t>(tiles, 1u), 1u);
+    const uint64_t step = segs_per_launch * kSegmentSamplesMax;
+    for (uint64_t done = 0u; done < count; done += step) {
+        js.p.sample_begin = first + (uint32_t)done;
+        js.p.sample_count = (uint32_t)std::min<uint64_t>(step, count - done);
+        const int st = enqueue_jobs(ctx, &js, 1u, stream, queue_heads, may_allocate);
+        if (st != RT_OK)
+            return st;
+    }
     return RT_OK;
 }
 
@@ -713,6 +779,33 @@ int rt_accumulate_device(rt_context *ctx, const rt_camera *cam, const rt_params 
     RT_DEVICE(ctx);
     const Region rg = clip_region(*params, xstart, ystart, xsize, ysize);
     return enqueue_accumulate(ctx, cam, params, rg, d_sums, (hipStream_t)stream);
+}
+
+int rt_accumulate_batch_device(rt_context *ctx, const rt_job *jobs, uint32_t n_jobs, void *stream)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
+    if (n_jobs == 0u)
+        return RT_OK;
+    if (!jobs)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null jobs");
+    if (n_jobs > RT_MAX_JOBS)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "more than RT_MAX_JOBS jobs in one launch");
+    JobSpec specs[RT_MAX_JOBS];
+    for (uint32_t i = 0; i < n_jobs; ++i) {
+        const int st = check_params(ctx, &jobs[i].cam, &jobs[i].params);
+        if (st != RT_OK)
+            return st;
+        if (!jobs[i].d_sums)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null d_sums");
+        specs[i].cam = &jobs[i].cam;
+        specs[i].p = jobs[i].params;
+        specs[i].rg = clip_region(jobs[i].params, jobs[i].xstart, jobs[i].ystart, jobs[i].xsize, jobs[i].ysize);
+        specs[i].d_sums = jobs[i].d_sums;
+    }
+    RT_DEVICE(ctx);
+    return enqueue_jobs(ctx, specs, n_jobs, (hipStream_t)stream);
 }
 
 int rt_resolve_device(rt_context *ctx, const uint32_t *d_sums, uint32_t width, uint32_t height,
@@ -1163,21 +1256,32 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_WORKGROUPS_PER_CU takes 0..8");
         ctx->wg_per_cu_override = (int)value;
         return RT_OK;
-    case RT_OPT_BVH_LEAF_SPHERES:
-        if (value < 1 || value > kBvhLeafMax)
-            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_LEAF_SPHERES takes 1..15");
-        if (ctx->bvh_leaf_max != (int)value) {
+    case RT_OPT_BVH_LEAF_SPHERES: {
+        if (value < 0 || value > kBvhLeafMax)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_LEAF_SPHERES takes 0 (by scene size) or 1..15");
+        const int before = chosen_leaf_spheres(ctx);
+        ctx->bvh_leaf_max = (int)value;
+        if (ctx->bvh_ready && chosen_leaf_spheres(ctx) != before) { // the tree on the device has another shape
             RT_DEVICE(ctx);
             RT_HIP(ctx, hipDeviceSynchronize());
             drop_bvh(ctx);
-            ctx->bvh_leaf_max = (int)value;
         }
         break;
-    case RT_OPT_BVH_LDS_NODES:
+    }
+    case RT_OPT_BVH_LDS_NODES: {
         if (value < 0 || value > 2048)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_LDS_NODES takes 0..2048");
+        // the automatic leaf size depends on whether the tree is expected to fit LDS: a tree built for
+        // the old limit is dropped and (below) rebuilt when the new limit chooses another
+        const int before = chosen_leaf_spheres(ctx);
         ctx->bvh_lds_nodes_max = (uint32_t)value;
-        return RT_OK;
+        if (ctx->bvh_ready && chosen_leaf_spheres(ctx) != before) {
+            RT_DEVICE(ctx);
+            RT_HIP(ctx, hipDeviceSynchronize());
+            drop_bvh(ctx);
+        }
+        break;
+    }
     case RT_OPT_BVH_SUSPEND_LANES:
         if (value < 0 || value > 63)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_SUSPEND_LANES takes 0..63");
@@ -1215,6 +1319,34 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
     if (ctx->have_scene && chosen_filter(ctx) == kFilterBvh && !ctx->bvh_ready) {
         RT_DEVICE(ctx);
         return ensure_bvh(ctx);
+    }
+    return RT_OK;
+}
+
+int rt_get_option(rt_context *ctx, int option, int64_t *value)
+{
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
+    if (!value)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null value");
+    switch (option) {
+    case RT_OPT_FILTER:
+        *value = !ctx->filter_forced ? -1 : ctx->filter == kFilterExact ? 0 : ctx->filter == kFilterConservative ? 1
+                 : ctx->filter == kFilterMatrix ? 2 : 3;
+        break;
+    case RT_OPT_TILE_SPHERES: *value = ctx->tile_cap_max; break;
+    case RT_OPT_WORKGROUPS_PER_CU: *value = ctx->wg_per_cu_override; break;
+    case RT_OPT_BVH_LEAF_SPHERES: *value = ctx->bvh_leaf_max; break;
+    case RT_OPT_BVH_MIN_SPHERES: *value = ctx->bvh_auto_min; break;
+    case RT_OPT_BVH_LDS_NODES: *value = ctx->bvh_lds_nodes_max; break;
+    case RT_OPT_BVH_SUSPEND_LANES: *value = ctx->bvh_suspend_lanes; break;
+    case RT_OPT_CHUNKS_PER_WAVE: *value = ctx->chunks_per_wave; break;
+    case RT_OPT_SUBTILES: *value = ctx->subtiles_max; break;
+    case RT_OPT_DIRECT_ADD_SAMPLES: *value = ctx->direct_add_samples; break;
+    case RT_OPT_COUNT_WORK: *value = ctx->count_work ? 1 : 0; break;
+    default:
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option");
     }
     return RT_OK;
 }

@@ -70,6 +70,38 @@ struct BvhArgs {
     float radius2, rmin, rmin2w; // see BvhHost (radius2 >= radius^2)
 };
 
+// Most jobs one trace launch carries (rt_accumulate_batch_device).
+constexpr uint32_t kMaxJobs = 8;
+
+// One job of a trace launch: a camera, a frame, a range of samples and a set of tiles of a region, added
+// into the job's own sums.  The jobs of a launch share the scene, the scan, the generator's key and the
+// flags; their chunks form one work queue, job after job, so that waves which find a job's chunks all
+// handed out go on with the next job's while that job's last paths are still bouncing elsewhere.
+struct TraceJob {
+    rt_camera cam;
+    uint32_t width, height;
+    double inv_width, inv_height; // 1/(double)(float)width, 1/(double)(float)height, correctly rounded
+    double width_d, height_d;     // (double)(float)width, (double)(float)height
+    uint32_t sample_begin, sample_count;
+    int32_t max_depth;
+    // The chunks' sums are added to `sums` with atomics: the samples are cut into segments, or another
+    // job of the launch adds into the same memory.  Else with plain loads and stores (the launch's
+    // only writer of those pixels is the wave that owns the chunk).
+    uint32_t atomic_flush;
+    int32_t x0, y0, w, h;      // traced region
+    uint32_t tiles_x, tiles_y; // 8x8 tiles of the region
+    uint32_t tile_first, tile_stride; // the job's tiles: tile_first + k*tile_stride
+    // Work queue: a tile is cut into `subtiles` strips of 8/subtiles rows (1, 2 or 4; strips touch
+    // the same memory lines of `sums` as the whole tile) and its sample range into `segments` runs of seg_samples samples (the last
+    // may be shorter, none is empty).  The job's chunks are chunk_first .. chunk_first + n_chunks - 1 of
+    // the launch; its chunk c is tile k = c / (subtiles*segments), strip (c / segments) % subtiles,
+    // segment c % segments.  A strip clipped away by the region's edge is an empty chunk.
+    uint32_t chunk_first, n_chunks;
+    uint32_t subtiles, segments, seg_samples;
+    uint32_t reserved;
+    uint32_t *sums;            // full frame uint32 x3
+};
+
 struct TraceArgs {
     const Geom *geom;          // phase-1 records for `filter`, padded to a multiple of 128
     const Geom *exact;         // {centre, fl(r*r)}, same padding
@@ -81,36 +113,24 @@ struct TraceArgs {
     uint32_t stack_entry_bytes; // bounce stack entry: 2 while n <= 65536, else 4
     uint32_t aux_bytes;        // LDS between the tiles and the bounce stack: operand staging or traversal stack
     BvhArgs bvh;               // kFilterBvh only
-    rt_camera cam;
-    uint32_t width, height;
-    double inv_width, inv_height; // 1/(double)(float)width, 1/(double)(float)height, correctly rounded
-    double width_d, height_d;     // (double)(float)width, (double)(float)height
-    uint32_t sample_begin, sample_count;
-    int32_t max_depth;
+    int32_t max_depth;         // the largest of the jobs' (sizes the bounce stack in LDS)
     uint32_t flags;            // RT_FLAG_*
     uint32_t count_work;       // launch the counting build: tallies of executed work go to rays[2..4]
     uint32_t key0, key1;
-    int32_t x0, y0, w, h;      // traced region
-    uint32_t tiles_x, tiles_y; // 8x8 tiles of the region
-    uint32_t tile_first, tile_stride; // the call's tiles: tile_first + k*tile_stride
-    // Work queue: a tile is cut into `subtiles` strips of 8/subtiles rows (1, 2 or 4; strips touch
-    // the same memory lines of `sums` as the whole tile) and its sample range into `segments` runs of seg_samples samples (the last
-    // may be shorter, none is empty).  Chunk c is tile k = c / (subtiles*segments), strip
-    // (c / segments) % subtiles, segment c % segments.  A strip clipped away by the region's
-    // edge is an empty chunk.  With segments > 1 several waves add into the same pixels of `sums`.
-    uint32_t n_chunks, subtiles, segments, seg_samples;
+    uint32_t n_jobs;           // 1 .. kMaxJobs
+    uint32_t n_chunks;         // of all jobs
     uint32_t n_queues;         // heads of the work queue in use: a power of two <= min(kQueues, workgroups)
     // Chunks of very few samples: every path adds its colour to `sums` itself (three atomics) instead of
     // through the wave's two per-chunk accumulators, so a wave never waits for a chunk to drain
-    // before it may pull the next one.
+    // before it may pull the next one.  Single-job launches only.
     uint32_t direct_add;
-    uint32_t *sums;            // full frame uint32 x3
     unsigned long long *rays;  // kCounterSlots x kCounterWords counters; a workgroup adds to slot blockIdx % kCounterSlots:
                                // [0] rays, [1] wave passes over the sphere list; counting build: [2] hierarchy
                                // nodes visited, [3] exact discriminants, [4] root evaluations, [8..] section tallies
     // Work queue heads, zeroed before launch: kQueues counters kQueueStride words apart; queue q
     // hands out chunks q, q + kQueues, q + 2 kQueues, ...
     uint32_t *chunk_counter;
+    TraceJob jobs[kMaxJobs];
 };
 
 struct ResolveArgs {

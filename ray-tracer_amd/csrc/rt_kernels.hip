@@ -305,7 +305,8 @@ trace_kernel(const TraceArgs a)
     uint32_t s_total0 = 0u, s_total1 = 0u, s_done0 = 0u, s_done1 = 0u;
     int s_x0[2] = { 0, 0 }, s_y0[2] = { 0, 0 }, s_tw[2] = { 1, 1 }, s_npx[2] = { 1, 1 };
     uint32_t s_smp[2] = { 0u, 0u }; // first sample of the chunk's segment
-    bool queue_empty = (a.sample_count == 0u);
+    uint32_t s_job[2] = { 0u, 0u }; // the launch's job the chunk belongs to
+    bool queue_empty = (a.n_chunks == 0u);
 
     // per-lane path state
     bool active = false;
@@ -338,8 +339,8 @@ trace_kernel(const TraceArgs a)
             cb = to_byte(sp->color[2] * (float)cb);
         }
         const ConstArgs kt = fresh_args();
-        if (kt->direct_add) {
-            uint32_t *dst = kt->sums + (size_t)pixel * 3u;
+        if (kt->direct_add) { // (single-job launches only)
+            uint32_t *dst = kt->jobs[0].sums + (size_t)pixel * 3u;
             atomicAdd(dst + 0, (uint32_t)cr);
             atomicAdd(dst + 1, (uint32_t)cg);
             atomicAdd(dst + 2, (uint32_t)cb);
@@ -361,14 +362,17 @@ trace_kernel(const TraceArgs a)
                 if (total != 0u && done == total) {
                     if (lane < s_npx[sl]) {
                         const ConstArgs ka = fresh_args();
+                        const uint32_t job = __builtin_amdgcn_readfirstlane(s_job[sl]);
                         const int ly = lane / s_tw[sl], lx = lane - ly * s_tw[sl];
-                        uint32_t *dst = ka->sums + ((size_t)(s_x0[sl] + lx) + (size_t)(s_y0[sl] + ly) * ka->width) * 3u;
+                        uint32_t *dst = ka->jobs[job].sums +
+                                        ((size_t)(s_x0[sl] + lx) + (size_t)(s_y0[sl] + ly) * ka->jobs[job].width) * 3u;
                         uint32_t *src = acc + sl * 128 + lane * 2;
                         const uint32_t sum[3] = { src[0] & 0xffffu, src[0] >> 16, src[1] };
                         src[0] = src[1] = 0u;
+                        const bool with_atomics = ka->jobs[job].atomic_flush != 0u;
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch) {
-                            if (a.segments > 1u)
+                            if (with_atomics)
                                 atomicAdd(dst + ch, sum[ch]);
                             else
                                 dst[ch] += sum[ch];
@@ -435,32 +439,40 @@ trace_kernel(const TraceArgs a)
                         t_dry = wall_clock64();
                     break;
                 }
-                uint32_t k = c, sub = 0u, seg = 0u;
-                const uint32_t per_tile = kq->subtiles * kq->segments;
+                // the job whose chunk this is (the jobs' chunks follow each other in the launch's numbering)
+                uint32_t job = 0u;
+                while (job + 1u < kq->n_jobs && c >= kq->jobs[job + 1u].chunk_first)
+                    ++job;
+                job = __builtin_amdgcn_readfirstlane(job);
+                const auto *kj = &kq->jobs[job];
+                uint32_t k = c - kj->chunk_first, sub = 0u, seg = 0u;
+                const uint32_t per_tile = kj->subtiles * kj->segments;
                 if (per_tile > 1u) {
-                    k = c / per_tile;
-                    const uint32_t r = c - k * per_tile;
-                    sub = r / kq->segments;
-                    seg = r - sub * kq->segments;
+                    const uint32_t cj = k;
+                    k = cj / per_tile;
+                    const uint32_t r = cj - k * per_tile;
+                    sub = r / kj->segments;
+                    seg = r - sub * kj->segments;
                 }
-                const uint32_t seg_first = seg * kq->seg_samples;
-                const uint32_t seg_count = min(kq->seg_samples, kq->sample_count - seg_first);
-                const uint32_t t = kq->tile_first + k * kq->tile_stride;
-                const uint32_t ty = t / kq->tiles_x, tx = t - ty * kq->tiles_x;
+                const uint32_t seg_first = seg * kj->seg_samples;
+                const uint32_t seg_count = min(kj->seg_samples, kj->sample_count - seg_first);
+                const uint32_t t = kj->tile_first + k * kj->tile_stride;
+                const uint32_t ty = t / kj->tiles_x, tx = t - ty * kj->tiles_x;
                 // the tile, clipped to the region, then the chunk's strip of it (possibly empty)
-                const int x0 = kq->x0 + (int)tx * kTileW;
-                int y0 = kq->y0 + (int)ty * kTileH;
-                const int tw = min(kTileW, kq->x0 + kq->w - x0);
-                int th = min(kTileH, kq->y0 + kq->h - y0);
-                if (kq->subtiles > 1u) { // strips of whole tile rows: the same memory lines as the tile's
-                    const int rows = kTileH / (int)kq->subtiles;
+                const int x0 = kj->x0 + (int)tx * kTileW;
+                int y0 = kj->y0 + (int)ty * kTileH;
+                const int tw = min(kTileW, kj->x0 + kj->w - x0);
+                int th = min(kTileH, kj->y0 + kj->h - y0);
+                if (kj->subtiles > 1u) { // strips of whole tile rows: the same memory lines as the tile's
+                    const int rows = kTileH / (int)kj->subtiles;
                     y0 += (int)sub * rows;
                     th = min(rows, th - (int)sub * rows);
                 }
                 const int npx = (tw > 0 && th > 0) ? tw * th : 0;
                 cur = fs;
                 s_x0[fs] = x0; s_y0[fs] = y0; s_tw[fs] = max(tw, 1); s_npx[fs] = npx;
-                s_smp[fs] = kq->sample_begin + seg_first;
+                s_smp[fs] = kj->sample_begin + seg_first;
+                s_job[fs] = job;
                 w_next = 0u;
                 w_smp = 0u;
                 w_pix = 0u;
@@ -489,24 +501,25 @@ trace_kernel(const TraceArgs a)
                 const int ly = (int)(uint32_t)(((float)p + 0.5f) * w_inv_tw);
                 const int lx = (int)p - ly * ch_tw;
                 const int px = ch_x0 + lx, py = ch_y0 + ly;
-                pixel = (uint32_t)px + (uint32_t)py * a.width;
+                const ConstArgs ka = fresh_args();
+                const auto *kj = &ka->jobs[__builtin_amdgcn_readfirstlane(s_job[cur])];
+                pixel = (uint32_t)px + (uint32_t)py * kj->width;
                 sample = s_smp[cur] + w_smp + s;
                 acc_at = (uint32_t)cur * 128u + p * 2u;
                 call = 0u;
                 uint32_t w[4];
                 philox4x32_10(pixel, sample, call++, a.key0, a.key1, w);
-                const ConstArgs ka = fresh_args();
                 rt_camera cam;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    cam.origin[q] = ka->cam.origin[q];
-                    cam.bottom_left[q] = ka->cam.bottom_left[q];
-                    cam.horizontal[q] = ka->cam.horizontal[q];
-                    cam.vertical[q] = ka->cam.vertical[q];
+                    cam.origin[q] = kj->cam.origin[q];
+                    cam.bottom_left[q] = kj->cam.bottom_left[q];
+                    cam.horizontal[q] = kj->cam.horizontal[q];
+                    cam.vertical[q] = kj->cam.vertical[q];
                 }
-                camera_ray(cam, ka->width_d, ka->height_d, ka->inv_width, ka->inv_height, px, py, (double)unit_float(w[0]),
+                camera_ray(cam, kj->width_d, kj->height_d, kj->inv_width, kj->inv_height, px, py, (double)unit_float(w[0]),
                            (double)unit_float(w[1]), ray);
-                depth = a.max_depth; // >= 1: the host does not launch for RAY_DEPTH <= 0
+                depth = kj->max_depth; // >= 1: the host gives no job with RAY_DEPTH <= 0 to a launch
                 level = 0;
                 active = true;
             }
@@ -799,7 +812,7 @@ trace_kernel(const TraceArgs a)
                 }
                 const ConstArgs kt = fresh_args();
                 if (kt->direct_add) {
-                    uint32_t *dst = kt->sums + (size_t)pixel * 3u;
+                    uint32_t *dst = kt->jobs[0].sums + (size_t)pixel * 3u;
                     atomicAdd(dst + 0, (uint32_t)to_byte(fr));
                     atomicAdd(dst + 1, (uint32_t)to_byte(fg));
                     atomicAdd(dst + 2, (uint32_t)to_byte(fb));

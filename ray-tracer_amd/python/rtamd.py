@@ -29,11 +29,11 @@ FILTER_AUTO, FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX, FILTER_BVH = -1, 
 # every symbol include/rt_mi355x.h declares
 EXPORTS = [
     "rt_abi_version", "rt_status_string", "rt_last_error", "rt_create", "rt_destroy", "rt_set_scene",
-    "rt_camera_init", "rt_render", "rt_render_progressive", "rt_render_device", "rt_render_device_static", "rt_accumulate_device", "rt_resolve_device",
+    "rt_camera_init", "rt_render", "rt_render_progressive", "rt_render_device", "rt_render_device_static", "rt_accumulate_device", "rt_accumulate_batch_device", "rt_resolve_device",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_device_count", "rt_multi_uses_rccl",
     "rt_multi_context", "rt_multi_set_scene", "rt_multi_set_option", "rt_multi_render", "rt_multi_render_device",
     "rt_multi_synchronize", "rt_multi_get_stats", "rt_multi_reset_stats",
-    "rt_tile_block_bytes", "rt_pack_tiles_device", "rt_unpack_tiles_device", "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_accel_selfcheck", "rt_get_stats", "rt_reset_stats", "rt_get_work_profile",
+    "rt_tile_block_bytes", "rt_pack_tiles_device", "rt_unpack_tiles_device", "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_get_option", "rt_accel_selfcheck", "rt_get_stats", "rt_reset_stats", "rt_get_work_profile",
 ]
 
 
@@ -60,6 +60,22 @@ class Params(C.Structure):
         ("flags", C.c_uint32),
         ("reserved", C.c_uint32),
     ]
+
+
+class Job(C.Structure):
+    """rt_job: one rt_accumulate_device call as an entry of rt_accumulate_batch_device."""
+    _fields_ = [
+        ("cam", Camera),
+        ("params", Params),
+        ("xstart", C.c_int32),
+        ("ystart", C.c_int32),
+        ("xsize", C.c_int32),
+        ("ysize", C.c_int32),
+        ("d_sums", C.c_void_p),
+    ]
+
+
+MAX_JOBS = 8
 
 
 class Stats(C.Structure):
@@ -139,7 +155,10 @@ def load():
     L.rt_primary_hits.argtypes = [vp, C.POINTER(Camera), u32, u32, vp]
     L.rt_primary_hits_device.argtypes = [vp, C.POINTER(Camera), u32, u32, vp, vp]
     L.rt_intersect.argtypes = [vp, vp, u32, vp]
+    if hasattr(L, "rt_accumulate_batch_device"):  # absent from older builds kept for A/B timing (RTAMD_LIBRARY)
+        L.rt_accumulate_batch_device.argtypes = [vp, C.POINTER(Job), u32, vp]
     L.rt_set_option.argtypes = [vp, i, C.c_int64]
+    L.rt_get_option.argtypes = [vp, i, C.POINTER(C.c_int64)]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_reset_stats.argtypes = [vp]
     if hasattr(L, "rt_get_work_profile"):  # absent from older builds kept for A/B timing (RTAMD_LIBRARY)
@@ -247,6 +266,18 @@ class Context:
             tile = (0, 0, p.width, p.height)
         self._check(self._L.rt_accumulate_device(self._h, C.byref(cam), C.byref(p), *tile, d_sums, stream))
 
+    def accumulate_batch_device(self, jobs, stream=None):
+        """jobs: sequence of (cam, params, d_sums) or (cam, params, d_sums, tile) -- one launch for all of them."""
+        arr = (Job * len(jobs))()
+        for k, job in enumerate(jobs):
+            cam, p, d_sums = job[:3]
+            tile = job[3] if len(job) > 3 and job[3] is not None else (0, 0, p.width, p.height)
+            arr[k].cam = cam
+            arr[k].params = p
+            arr[k].xstart, arr[k].ystart, arr[k].xsize, arr[k].ysize = tile
+            arr[k].d_sums = d_sums
+        self._check(self._L.rt_accumulate_batch_device(self._h, arr, len(jobs), stream))
+
     def resolve_device(self, d_sums, width, height, spp_div, d_rgb, tile=None, stream=None, flags=0):
         if tile is None:
             tile = (0, 0, width, height)
@@ -286,6 +317,11 @@ class Context:
 
     def set_option(self, option, value):
         self._check(self._L.rt_set_option(self._h, option, value))
+
+    def get_option(self, option):
+        v = C.c_int64(0)
+        self._check(self._L.rt_get_option(self._h, option, C.byref(v)))
+        return v.value
 
     def stats(self):
         s = Stats()

@@ -28,11 +28,22 @@ def torch():
     return torch
 
 
+ALL_OPTIONS = [rtamd.OPT_FILTER, rtamd.OPT_TILE_SPHERES, rtamd.OPT_WORKGROUPS_PER_CU, rtamd.OPT_BVH_LEAF_SPHERES,
+               rtamd.OPT_BVH_MIN_SPHERES, rtamd.OPT_BVH_LDS_NODES, rtamd.OPT_BVH_SUSPEND_LANES, rtamd.OPT_CHUNKS_PER_WAVE,
+               rtamd.OPT_SUBTILES, rtamd.OPT_COUNT_WORK, rtamd.OPT_DIRECT_ADD_SAMPLES]
+
+
 @pytest.fixture(scope="module")
 def ctx():
     c = rtamd.Context(0)
+    c.shipped = {o: c.get_option(o) for o in ALL_OPTIONS}  # what a fresh context runs with
     yield c
     c.close()
+
+
+def restore_shipped_options(c):
+    for o, v in c.shipped.items():
+        c.set_option(o, v)
 
 
 def c3_scene():
@@ -421,7 +432,8 @@ def test_split_sample_ranges_give_the_same_sums(ctx, torch, filt):
     _, sums_o, rays_o = O.trace_tile(sc, O.camera(*C3_CAM), W, H, SPP, D, O.RNG_COUNTER, seed=21, want_sums=True)
     d_sums = torch.zeros(H * W * 3, dtype=torch.int32, device="cuda")
     try:
-        for per_wave, subtiles in ((0, 4), (1, 1), (16, 1), (256, 1), (1, 2), (256, 2), (1, 4), (16, 4), (256, 4)):
+        for per_wave, subtiles in ((0, 4), (1, 1), (16, 1), (32, 1), (256, 1), (1, 2), (32, 2), (256, 2), (1, 4), (16, 4),
+                                   (32, 4), (256, 4)):
             ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, per_wave)
             ctx.set_option(rtamd.OPT_SUBTILES, subtiles)
             d_sums.zero_()
@@ -442,9 +454,7 @@ def test_split_sample_ranges_give_the_same_sums(ctx, torch, filt):
         assert np.array_equal(d_sums.cpu().numpy().view(np.uint32).reshape(H, W, 3), sums_o)
         assert ctx.stats().rays == rays_o
     finally:
-        ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, 16)
-        ctx.set_option(rtamd.OPT_SUBTILES, 4)
-        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
+        restore_shipped_options(ctx)
 
 
 @pytest.mark.parametrize("filt", [rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_BVH])
@@ -500,7 +510,7 @@ def test_random_calls_do_not_depend_on_how_the_queue_cuts_them(ctx, torch):
                              tile_first=first, tile_stride=stride)
             ctx.set_option(rtamd.OPT_FILTER, int(rs.choice([rtamd.FILTER_AUTO, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_BVH])))
             out = []
-            for per_wave, subtiles in ((0, 4), (int(rs.choice([1, 16, 256])), int(rs.choice([1, 2, 4])))):
+            for per_wave, subtiles in ((0, 4), (int(rs.choice([1, 16, 32, 256])), int(rs.choice([1, 2, 4])))):
                 ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, per_wave)
                 ctx.set_option(rtamd.OPT_SUBTILES, subtiles)
                 d_sums = torch.full((H * W * 3,), 5, dtype=torch.int32, device="cuda")
@@ -510,9 +520,76 @@ def test_random_calls_do_not_depend_on_how_the_queue_cuts_them(ctx, torch):
                 out.append((d_sums.cpu().numpy(), ctx.stats().rays))
             assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1], (case, W, H, spp, s0, cnt, stride, first, tile)
     finally:
-        ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, 16)
-        ctx.set_option(rtamd.OPT_SUBTILES, 4)
-        ctx.set_option(rtamd.OPT_FILTER, rtamd.FILTER_AUTO)
+        restore_shipped_options(ctx)
+
+
+@pytest.mark.parametrize("filt", [rtamd.FILTER_AUTO, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX])
+def test_batched_jobs_add_what_separate_calls_add(ctx, torch, filt):
+    """rt_accumulate_batch_device: several jobs in one launch (one work queue, job after job) leave in
+    every job's sums exactly what one rt_accumulate_device call per job leaves -- frames of different
+    sizes and cameras into buffers of their own, sample slices and interleaved tile sets of one frame
+    into one buffer, ragged regions, different depths -- and trace the same number of rays; the first
+    job's frame also equals the oracle's."""
+    sc = c3_scene()
+    ctx.set_scene(sc)
+    ctx.set_option(rtamd.OPT_FILTER, filt)
+    try:
+        cam_a = rtamd.make_camera(*C3_CAM)
+        cam_b = rtamd.make_camera((5.0, 1.5, -9.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 35.0)
+        shapes = [(61, 43, 9, 6), (128, 72, 4, 8), (33, 90, 16, 3)]
+        bufs = [torch.zeros(h * w * 3, dtype=torch.int32, device="cuda") for w, h, _, _ in shapes]
+        shared = torch.zeros(80 * 48 * 3, dtype=torch.int32, device="cuda")
+        jobs = []
+        for (w, h, spp, d), buf, cam in zip(shapes, bufs, (cam_a, cam_b, cam_a)):
+            jobs.append((cam, rtamd.params(w, h, spp, d, seed=77), buf.data_ptr()))
+        jobs[2] = jobs[2] + ((-4, 10, 30, 200),)  # a region hanging over the frame
+        # one 80x48 frame of 24 spp as two sample slices over two tile sets each: four jobs, one buffer
+        for s0, cnt in ((0, 10), (10, 14)):
+            for first in range(2):
+                p = rtamd.params(80, 48, 24, 8, seed=77, sample_begin=s0, sample_count=cnt, tile_first=first, tile_stride=2)
+                jobs.append((cam_b, p, shared.data_ptr()))
+        assert len(jobs) == 7
+        ctx.reset_stats()
+        ctx.accumulate_batch_device(jobs)
+        torch.cuda.synchronize()
+        rays_batch = ctx.stats().rays
+        got = [b.cpu().numpy().copy() for b in bufs] + [shared.cpu().numpy().copy()]
+        for b in bufs + [shared]:
+            b.zero_()
+        ctx.reset_stats()
+        for job in jobs:
+            ctx.accumulate_device(job[0], job[1], job[2], tile=job[3] if len(job) > 3 else None)
+        torch.cuda.synchronize()
+        assert ctx.stats().rays == rays_batch
+        for g, b in zip(got, bufs + [shared]):
+            assert np.array_equal(g, b.cpu().numpy())
+        w, h, spp, d = shapes[0]
+        _, sums_o, _ = O.trace_tile(sc, O.camera(*C3_CAM), w, h, spp, d, O.RNG_COUNTER, seed=77, want_sums=True)
+        assert np.array_equal(got[0].view(np.uint32).reshape(h, w, 3), sums_o)
+        _, sums_o, _ = O.trace_tile(sc, O.camera((5.0, 1.5, -9.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 35.0), 80, 48, 24, 8,
+                                    O.RNG_COUNTER, seed=77, want_sums=True)
+        assert np.array_equal(got[3].view(np.uint32).reshape(48, 80, 3), sums_o)
+        # every cut of the work queue
+        for per_wave, subtiles in ((0, 4), (1, 1), (32, 2), (256, 4)):
+            ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, per_wave)
+            ctx.set_option(rtamd.OPT_SUBTILES, subtiles)
+            for b in bufs + [shared]:
+                b.zero_()
+            ctx.accumulate_batch_device(jobs)
+            torch.cuda.synchronize()
+            for g, b in zip(got, bufs + [shared]):
+                assert np.array_equal(g, b.cpu().numpy()), (per_wave, subtiles)
+        # jobs of one launch share the generator's key and the flags; at most RT_MAX_JOBS of them
+        other_seed = (cam_a, rtamd.params(61, 43, 9, 6, seed=78), bufs[0].data_ptr())
+        with pytest.raises(rtamd.RtError):
+            ctx.accumulate_batch_device([jobs[0], other_seed])
+        with pytest.raises(rtamd.RtError):
+            ctx.accumulate_batch_device([jobs[0]] * (rtamd.MAX_JOBS + 1))
+        # jobs with nothing to trace are skipped
+        ctx.accumulate_batch_device([(cam_a, rtamd.params(61, 43, 9, 0, seed=77), bufs[0].data_ptr())])
+        torch.cuda.synchronize()
+    finally:
+        restore_shipped_options(ctx)
 
 
 def test_executed_work_counters(ctx):
@@ -673,7 +750,10 @@ def test_converged_random_spheres_vs_reference_image(ctx):
 
 
 def test_full_size_frame_properties(ctx, torch):
-    """1920x1080, 64 spp, depth 8, 500 spheres: determinism, partition invariance, sampled oracle pixels."""
+    """1920x1080, 64 spp, depth 8, 500 spheres: determinism, partition invariance, sampled oracle pixels.
+    This is the frame bench.py times: it must run under the options a fresh context ships with."""
+    assert {o: ctx.get_option(o) for o in ALL_OPTIONS} == ctx.shipped
+    assert ctx.shipped[rtamd.OPT_CHUNKS_PER_WAVE] == 32 and ctx.shipped[rtamd.OPT_FILTER] == rtamd.FILTER_AUTO
     sc = c3_scene()
     ctx.set_scene(sc)
     cam = rtamd.make_camera(*C3_CAM)
