@@ -259,13 +259,17 @@ int chosen_leaf_spheres(const rt_context *ctx)
 
 // Builds the hierarchy over the current scene and copies it to the device (once per scene
 // and leaf size).
-int ensure_bvh(rt_context *ctx)
+// `prebuilt` (may be null): the hierarchy another context built over the same list with the same leaf size.
+int ensure_bvh(rt_context *ctx, const BvhHost *prebuilt = nullptr)
 {
     if (ctx->bvh_ready)
         return RT_OK;
     drop_bvh(ctx);
     BvhHost &b = ctx->bvh;
-    bvh_build(ctx->h_spheres.data(), ctx->h_exact.data(), ctx->n_spheres, chosen_leaf_spheres(ctx), b);
+    if (prebuilt)
+        b = *prebuilt;
+    else
+        bvh_build(ctx->h_spheres.data(), ctx->h_exact.data(), ctx->n_spheres, chosen_leaf_spheres(ctx), b);
     if (b.levels > 96u)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "hierarchy deeper than 96 levels");
     // the kernels follow child references and leaf ranges without bounds checks: make sure on the
@@ -348,8 +352,10 @@ struct JobSpec {
 // each into its own sums; same seed and flags).  `queue_heads` = the work queue to use (null: the
 // context's own); with `may_allocate` false nothing is allocated on the way (the hierarchy must be on
 // the device already).
+// `ordered` false (a stream under graph capture): the launch is not tied to the context's previous
+// trace launch by an event -- the caller's graph orders it.
 int enqueue_jobs(rt_context *ctx, const JobSpec *specs, uint32_t n, hipStream_t stream, uint32_t *queue_heads = nullptr,
-                 bool may_allocate = true)
+                 bool may_allocate = true, bool ordered = true)
 {
     TraceArgs a;
     memset(&a, 0, sizeof a);
@@ -515,12 +521,17 @@ int enqueue_jobs(rt_context *ctx, const JobSpec *specs, uint32_t n, hipStream_t 
     while (a.n_queues * 2u <= kQueues && a.n_queues * 2u <= n_wg)
         a.n_queues *= 2u;
 
-    if (ctx->trace_enqueued)
+    if (ordered && ctx->trace_enqueued)
         RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_trace, 0));
-    RT_HIP(ctx, hipMemsetAsync(a.chunk_counter, 0, kQueues * kQueueStride * sizeof(uint32_t), stream));
+    if (ordered)
+        RT_HIP(ctx, hipMemsetAsync(a.chunk_counter, 0, kQueues * kQueueStride * sizeof(uint32_t), stream));
+    else // under graph capture: a kernel, which every replay runs
+        RT_HIP(ctx, launch_zero(a.chunk_counter, kQueues * kQueueStride * sizeof(uint32_t), stream));
     RT_HIP(ctx, launch_trace(a, n_wg, stream));
-    RT_HIP(ctx, hipEventRecord(ctx->ev_trace, stream));
-    ctx->trace_enqueued = true;
+    if (ordered) {
+        RT_HIP(ctx, hipEventRecord(ctx->ev_trace, stream));
+        ctx->trace_enqueued = true;
+    }
     return RT_OK;
 }
 
@@ -528,7 +539,7 @@ int enqueue_jobs(rt_context *ctx, const JobSpec *specs, uint32_t n, hipStream_t 
 // segments outnumber what one launch's work queue can count, its sample range in several launches.
 int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p, const Region &rg,
                        uint32_t *d_sums, hipStream_t stream, uint32_t *queue_heads = nullptr,
-                       bool may_allocate = true)
+                       bool may_allocate = true, bool ordered = true)
 {
     JobSpec js = { cam, *p, rg, d_sums };
     const uint32_t first = p->sample_begin, count = p->sample_count ? p->sample_count : p->spp;
@@ -536,18 +547,29 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
     const uint64_t tiles = (uint64_t)((rg.w + kTileW - 1) / kTileW) * (uint64_t)((rg.h + kTileH - 1) / kTileH);
     const uint64_t segs = (count + kSegmentSamplesMax - 1u) / kSegmentSamplesMax;
     if (tiles * segs <= 0x3fffffffull)
-        return enqueue_jobs(ctx, &js, 1u, stream, queue_heads, may_allocate);
+        return enqueue_jobs(ctx, &js, 1u, stream, queue_heads, may_allocate, ordered);
     const uint64_t segs_per_launch = std::max<uint64_t>(0x3fffffffull / std::max<uint64_t>(tiles, 1u), 1u);
     const uint64_t step = segs_per_launch * kSegmentSamplesMax;
     for (uint64_t done = 0u; done < count; done += step) {
         js.p.sample_begin = first + (uint32_t)done;
         js.p.sample_count = (uint32_t)std::min<uint64_t>(step, count - done);
-        const int st = enqueue_jobs(ctx, &js, 1u, stream, queue_heads, may_allocate);
+        const int st = enqueue_jobs(ctx, &js, 1u, stream, queue_heads, may_allocate, ordered);
         if (st != RT_OK)
             return st;
     }
     return RT_OK;
 }
+
+// rt_render_device_static's scratch belongs to the GPU, not to a context: calls on one GPU are put in
+// order whatever context and stream they come through, by an event per device that every such call
+// waits for and records again.
+struct StaticScratchOrder {
+    std::mutex mtx;
+    hipEvent_t done = nullptr;
+    bool recorded = false;
+};
+constexpr int kMaxDevices = 64;
+StaticScratchOrder g_static_order[kMaxDevices];
 
 } // namespace
 
@@ -639,6 +661,13 @@ int rt_destroy(rt_context *ctx)
 
 int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n)
 {
+    return rtamd::set_scene_sharing_hierarchy(ctx, spheres, n, nullptr);
+}
+
+} // extern "C"
+
+int rtamd::set_scene_sharing_hierarchy(rt_context *ctx, const rt_sphere *spheres, uint32_t n, rt_context *donor)
+{
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::recursive_mutex> lock(ctx->mtx);
@@ -717,11 +746,20 @@ int rt_set_scene(rt_context *ctx, const rt_sphere *spheres, uint32_t n)
     ctx->scene_tame = tame;
     ctx->n_spheres = n;
     ctx->have_scene = true;
-    // the hierarchy, if the current options select it, goes to the device with the scene
-    if (chosen_filter(ctx) == kFilterBvh)
-        return ensure_bvh(ctx);
+    // the hierarchy, if the current options select it, goes to the device with the scene: built here, or
+    // taken over from a context that built it for the same list under the same options
+    if (chosen_filter(ctx) == kFilterBvh) {
+        const BvhHost *prebuilt = nullptr;
+        if (donor && donor != ctx && donor->bvh_ready && donor->n_spheres == n &&
+            chosen_leaf_spheres(donor) == chosen_leaf_spheres(ctx) &&
+            (n == 0u || memcmp(donor->h_spheres.data(), spheres, (size_t)n * sizeof(rt_sphere)) == 0))
+            prebuilt = &donor->bvh;
+        return ensure_bvh(ctx, prebuilt);
+    }
     return RT_OK;
 }
+
+extern "C" {
 
 // Camera::Camera, Source/main.cpp:420-438, in glm 0.9.8.5's operation order:
 // normalize(v) = v * (1 / sqrt(dot(v, v))), scalar * vector per component.
@@ -866,15 +904,42 @@ static int render_device(rt_context *ctx, const rt_camera *cam, const rt_params 
     const Region rg = clip_region(*params, xstart, ystart, xsize, ysize);
     if (rg.w == 0 || rg.h == 0)
         return RT_OK;
+    // A stream under graph capture takes no part in the event ordering below: an event recorded outside
+    // the capture cannot be waited for inside it, and one recorded inside it means nothing to later
+    // calls.  The captured sequence (memset, memset, trace, resolve) is ordered by the graph itself.
+    bool capturing = false;
+    if (use_static && s != nullptr) {
+        hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+        RT_HIP(ctx, hipStreamIsCapturing(s, &status));
+        capturing = status != hipStreamCaptureStatusNone;
+    }
     // Zero the rows of the region, trace, divide.  The sums are the context's own scratch and
     // calls may come on different streams (the reference's four strips share every row), so the
     // whole sequence is ordered behind the previous user of the scratch: ev_trace is waited for
-    // before the memset and recorded again behind the resolve.
-    if (ctx->trace_enqueued)
+    // before the memset and recorded again behind the resolve.  The static scratch is shared by all
+    // contexts of the GPU: its calls are ordered per device as well.
+    StaticScratchOrder *order = (use_static && !capturing && ctx->device < kMaxDevices) ? &g_static_order[ctx->device] : nullptr;
+    std::unique_lock<std::mutex> order_lock;
+    if (order) {
+        order_lock = std::unique_lock<std::mutex>(order->mtx);
+        if (!order->done)
+            RT_HIP(ctx, hipEventCreateWithFlags(&order->done, hipEventDisableTiming));
+        if (order->recorded)
+            RT_HIP(ctx, hipStreamWaitEvent(s, order->done, 0));
+    }
+    if (!capturing && ctx->trace_enqueued)
         RT_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_trace, 0));
     const size_t row_bytes = (size_t)params->width * 3u * sizeof(uint32_t);
-    RT_HIP(ctx, hipMemsetAsync((uint8_t *)sums + (size_t)rg.y0 * row_bytes, 0, (size_t)rg.h * row_bytes, s));
-    st = enqueue_accumulate(ctx, cam, params, rg, sums, s, queue_heads, !use_static);
+    if (capturing) {
+        // rows are 12 bytes per pixel: the zeroed span is widened to 16-byte bounds inside the scratch
+        // array (whose sums are all dead between calls)
+        const size_t first = ((size_t)rg.y0 * row_bytes) & ~(size_t)15u;
+        const size_t last = (((size_t)(rg.y0 + rg.h) * row_bytes) + 15u) & ~(size_t)15u;
+        RT_HIP(ctx, launch_zero((uint8_t *)sums + first, last - first, s));
+    } else {
+        RT_HIP(ctx, hipMemsetAsync((uint8_t *)sums + (size_t)rg.y0 * row_bytes, 0, (size_t)rg.h * row_bytes, s));
+    }
+    st = enqueue_accumulate(ctx, cam, params, rg, sums, s, queue_heads, !use_static, !capturing);
     if (st != RT_OK)
         return st;
     ResolveArgs a;
@@ -882,8 +947,14 @@ static int render_device(rt_context *ctx, const rt_camera *cam, const rt_params 
     a.width = params->width; a.height = params->height; a.spp_div = params->spp; a.flags = params->flags;
     a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
     RT_HIP(ctx, launch_resolve(a, s));
-    RT_HIP(ctx, hipEventRecord(ctx->ev_trace, s));
-    ctx->trace_enqueued = true;
+    if (!capturing) {
+        RT_HIP(ctx, hipEventRecord(ctx->ev_trace, s));
+        ctx->trace_enqueued = true;
+    }
+    if (order) {
+        RT_HIP(ctx, hipEventRecord(order->done, s));
+        order->recorded = true;
+    }
     return RT_OK;
 }
 

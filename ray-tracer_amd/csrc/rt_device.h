@@ -201,11 +201,17 @@ size_t trace_lds_bytes(int filter, uint32_t tile_cap, uint32_t aux_bytes, int32_
 
 hipError_t launch_trace(const TraceArgs &a, uint32_t n_workgroups, hipStream_t stream);
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream);
+// Zeroes `bytes` bytes at `dst` (both multiples of 16) with a kernel: what a captured stream uses instead of a memset.
+hipError_t launch_zero(void *dst, size_t bytes, hipStream_t stream);
 hipError_t launch_pack_tiles(const TilesArgs &a, hipStream_t stream);
 hipError_t launch_unpack_tiles(const TilesArgs &a, hipStream_t stream);
 hipError_t launch_add_sums(const AddArgs &a, hipStream_t stream);
 hipError_t launch_primary_hits(const HitsArgs &a, hipStream_t stream);
 hipError_t launch_intersect(const IntersectArgs &a, hipStream_t stream);
+// rt_set_scene for a context of a multi-device object: when `donor` (may be null) already holds the
+// hierarchy for this very list under the same options, its host copy is reused instead of built again.
+int set_scene_sharing_hierarchy(rt_context *ctx, const rt_sphere *spheres, uint32_t n, rt_context *donor);
+
 // Resident workgroups per CU of the trace kernel at this LDS size.
 hipError_t trace_occupancy(int filter, bool counting, size_t lds_bytes, int *workgroups_per_cu);
 

@@ -987,6 +987,16 @@ __global__ void __launch_bounds__(256) add_sums_kernel(const AddArgs a)
     }
 }
 
+// Zeroes `count` 16-byte units.  Used in place of hipMemsetAsync on a stream under graph capture:
+// replays of a captured memset of the frame's sums were seen to leave them as they were (every
+// replay after the first doubled the picture), a captured kernel runs every time.
+__global__ void __launch_bounds__(256) zero_kernel(uint4 *dst, size_t count)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        dst[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // Deterministic primary-ray closest-hit map (jitter 0.5): one lane per pixel,
 // the whole workgroup walks the sphere tiles together.
 __global__ void __launch_bounds__(256) primary_hits_kernel(const HitsArgs a, uint32_t tile_cap)
@@ -1170,6 +1180,20 @@ hipError_t trace_occupancy(int filter, bool counting, size_t lds_bytes, int *wor
         return RT_OCCUPANCY(kFilterShort);
     return RT_OCCUPANCY(kFilterConservative);
 #undef RT_OCCUPANCY
+}
+
+hipError_t launch_zero(void *dst, size_t bytes, hipStream_t stream)
+{
+    (void)hipGetLastError();
+    if (bytes == 0u)
+        return hipSuccess;
+    if (((uintptr_t)dst | bytes) & 15u)
+        return hipErrorInvalidValue;
+    const size_t count = bytes / 16u;
+    const size_t want = (count + 255u) / 256u;
+    hipLaunchKernelGGL(zero_kernel, dim3((uint32_t)(want > 2048u ? 2048u : want)), dim3(256), 0, stream,
+                       reinterpret_cast<uint4 *>(dst), count);
+    return hipGetLastError();
 }
 
 hipError_t launch_resolve(const ResolveArgs &a, hipStream_t stream)

@@ -14,8 +14,12 @@
 // The exchange runs over RCCL (ncclReduce; grouped ncclSend/ncclRecv), loaded with dlopen when a
 // multi-device object asks for it, or as direct peer copies over xGMI (the first device reads the
 // other devices' sums in an add kernel; blocks are hipMemcpyPeerAsync'ed into the gather buffer).
-// Peer copies are also what several logical ranks on ONE device use, which is how the whole of this
-// file except the RCCL calls themselves can be tested on a single-GPU machine.
+// Peer copies are also what several logical ranks on ONE device use.  The RCCL branch is the same code
+// for one device as for several -- every rank, the first included, sends its block and reduces its sums
+// -- so a one-device object over RCCL executes every RCCL call of this file (with itself as the only
+// peer).  What has NOT run anywhere is RCCL between distinct devices: no multi-GPU machine was available
+// to this build, which is why RT_EXCHANGE_AUTO takes peer copies whenever the first device can address
+// all others, and RCCL only where it cannot.
 //
 // Frames are double-buffered: every rank has a compute and an exchange stream and two sets of
 // buffers, so the exchange of frame k runs beside the tracing of frame k + 1.
@@ -198,7 +202,9 @@ int ensure_buffers(rt_multi *m, size_t sums_bytes, size_t block_bytes)
         for (int s = 0; s < kSlots; ++s) {
             if (hipMalloc((void **)&r.sums[s], sums_bytes) != hipSuccess)
                 return fail(m, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for a rank's sums");
-            if (i > 0 && hipMalloc((void **)&r.block[s], block_bytes) != hipSuccess)
+            // (over RCCL the first rank sends its block like every other; with peer copies it packs
+            // straight into the gather buffer)
+            if ((i > 0 || m->use_rccl) && hipMalloc((void **)&r.block[s], block_bytes) != hipSuccess)
                 return fail(m, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for a rank's tile block");
         }
     }
@@ -206,7 +212,6 @@ int ensure_buffers(rt_multi *m, size_t sums_bytes, size_t block_bytes)
     for (int s = 0; s < kSlots; ++s) {
         if (hipMalloc((void **)&m->blocks[s], n * block_bytes) != hipSuccess)
             return fail(m, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for the gather buffer");
-        m->ranks[0].block[s] = nullptr; // the first rank packs straight into the gather buffer
     }
     m->sums_bytes = sums_bytes;
     m->block_bytes = block_bytes;
@@ -326,7 +331,10 @@ int rt_multi_create(const int *device_ids, uint32_t n_devices, int exchange, rt_
                 st = RT_ERR_HIP; // no peer path between the devices
         }
     }
-    if (st == RT_OK && distinct && exchange != RT_EXCHANGE_PEER_COPY) {
+    // AUTO: peer copies wherever the first device reaches all others (the transport every test of this
+    // file has run over), RCCL only where it does not
+    const bool want_rccl = exchange == RT_EXCHANGE_RCCL || (exchange == RT_EXCHANGE_AUTO && !all_peers);
+    if (st == RT_OK && distinct && want_rccl) {
         std::string why;
         if (m->rccl.load(why)) {
             std::vector<ncclComm_t> comms(n_devices);
@@ -358,8 +366,9 @@ int rt_multi_set_scene(rt_multi *m, const rt_sphere *spheres, uint32_t n)
     if (!m)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::recursive_mutex> lock(m->mtx);
+    // the first rank builds the hierarchy (on the host: seconds for very long lists); the others take it over
     for (Rank &r : m->ranks)
-        RTM_RT(m, r, rt_set_scene(r.ctx, spheres, n));
+        RTM_RT(m, r, set_scene_sharing_hierarchy(r.ctx, spheres, n, &r == &m->ranks[0] ? nullptr : m->ranks[0].ctx));
     return RT_OK;
 }
 
@@ -387,11 +396,47 @@ int rt_multi_synchronize(rt_multi *m)
     return RT_OK;
 }
 
+} // extern "C"
+
+namespace {
+
+int enqueue_frame(rt_multi *m, const rt_camera *cam, const rt_params *params, int partition, uint8_t *d_rgb);
+
+} // namespace
+
+extern "C" {
+
 int rt_multi_render_device(rt_multi *m, const rt_camera *cam, const rt_params *params, int partition, uint8_t *d_rgb)
 {
     if (!m)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::recursive_mutex> lock(m->mtx);
+    DeviceGuard guard;
+    const int st = enqueue_frame(m, cam, params, partition, d_rgb);
+    if (st != RT_OK) {
+        // Part of the frame may be enqueued on some devices and not on others: wait for what is, and
+        // forget both slots' "left the buffers" events, so that the next frame starts from idle
+        // devices instead of on top of buffers something may still read.  (The error message is kept.)
+        const std::string why = m->error;
+        for (Rank &r : m->ranks) {
+            if (hipSetDevice(r.device) == hipSuccess) {
+                (void)hipStreamSynchronize(r.compute);
+                (void)hipStreamSynchronize(r.comm);
+            }
+            r.exchanged_valid[0] = r.exchanged_valid[1] = false;
+        }
+        (void)hipGetLastError();
+        m->error = why;
+    }
+    return st;
+}
+
+} // extern "C"
+
+namespace {
+
+int enqueue_frame(rt_multi *m, const rt_camera *cam, const rt_params *params, int partition, uint8_t *d_rgb)
+{
     if (!cam || !params || !d_rgb)
         return fail(m, RT_ERR_INVALID_ARGUMENT, "null camera, params or d_rgb");
     if (partition != RT_PARTITION_SAMPLES && partition != RT_PARTITION_TILES)
@@ -405,7 +450,6 @@ int rt_multi_render_device(rt_multi *m, const rt_camera *cam, const rt_params *p
     const uint32_t W = params->width, H = params->height;
     const size_t count = (size_t)W * H * 3u;
     const size_t bb = (size_t)rt_tile_block_bytes(W, H, 0u, n); // every rank's block padded to the first's
-    DeviceGuard guard;
     int st = ensure_buffers(m, count * sizeof(uint32_t), bb);
     if (st != RT_OK)
         return st;
@@ -437,7 +481,7 @@ int rt_multi_render_device(rt_multi *m, const rt_camera *cam, const rt_params *p
         if (has_work)
             RTM_RT(m, r, rt_accumulate_device(r.ctx, cam, &p, 0, 0, (int)W, (int)H, r.sums[slot], r.compute));
         if (tiles) {
-            uint8_t *dst = i == 0 ? m->blocks[slot] : r.block[slot];
+            uint8_t *dst = (i == 0 && !m->use_rccl) ? m->blocks[slot] : r.block[slot];
             RTM_RT(m, r, rt_pack_tiles_device(r.ctx, r.sums[slot], W, H, params->spp, params->flags & RT_FLAG_GAMMA2,
                                               i, n, dst, r.compute));
         }
@@ -446,18 +490,23 @@ int rt_multi_render_device(rt_multi *m, const rt_camera *cam, const rt_params *p
     }
 
     // ---- the exchange, on the exchange streams
-    if (n > 1u && m->use_rccl) {
+    if (m->use_rccl) {
+        // One group for all ranks' calls (one thread drives every communicator).  Sample slices: every
+        // rank's sums reduced in place into the first rank's.  Tiles: every rank, the first included,
+        // sends its block to the first, which receives block j at offset j of the gather buffer -- with
+        // one device this is the first rank sending to itself, the same calls as with eight.
         RTM_NCCL(m, m->rccl.GroupStart());
         for (uint32_t i = 0; i < n; ++i) {
             Rank &r = m->ranks[i];
             ncclResult_t e = ncclSuccess;
             if (!tiles) {
                 e = m->rccl.Reduce(r.sums[slot], r.sums[slot], count, ncclUint32, ncclSum, 0, r.nccl, r.comm);
-            } else if (i == 0) {
-                for (uint32_t j = 1; j < n && e == ncclSuccess; ++j)
-                    e = m->rccl.Recv(m->blocks[slot] + (size_t)j * bb, bb, ncclUint8, (int)j, r.nccl, r.comm);
             } else {
-                e = m->rccl.Send(r.block[slot], bb, ncclUint8, 0, r.nccl, r.comm);
+                if (i == 0)
+                    for (uint32_t j = 0; j < n && e == ncclSuccess; ++j)
+                        e = m->rccl.Recv(m->blocks[slot] + (size_t)j * bb, bb, ncclUint8, (int)j, r.nccl, r.comm);
+                if (e == ncclSuccess)
+                    e = m->rccl.Send(r.block[slot], bb, ncclUint8, 0, r.nccl, r.comm);
             }
             if (e != ncclSuccess) {
                 (void)m->rccl.GroupEnd();
@@ -509,6 +558,10 @@ int rt_multi_render_device(rt_multi *m, const rt_camera *cam, const rt_params *p
     ++m->frames;
     return RT_OK;
 }
+
+} // namespace
+
+extern "C" {
 
 int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_params *params, int partition, uint8_t *rgb)
 {

@@ -1,8 +1,12 @@
 """rt_multi_*: one frame over several devices from one host process (the reference's TraceScene,
 Source/main.cpp:647-659, with devices in place of its four threads).  A one-GPU machine runs it with
-one device (the RCCL calls execute with a single rank) and with several logical ranks sharing the
-device (peer-copy exchange): every split, buffer rotation and exchange step except RCCL between
-distinct devices.  The assembled frame must be the single-context frame, bit for bit."""
+one device over RCCL -- the RCCL branch is the same code for one rank as for several, so ncclReduce
+(in place), ncclSend / ncclRecv (the rank sending its tile block to itself) and the group calls all
+execute, with a single rank -- and with several logical ranks sharing the device (peer-copy exchange):
+every split, buffer rotation and exchange step.  What a one-GPU machine cannot run is RCCL (or peer
+copies) between DISTINCT devices: test_multi_over_distinct_devices does, and skips where fewer than two GPUs
+exist.
+The assembled frame must be the single-context frame, bit for bit."""
 import ctypes as C
 import os
 import subprocess
@@ -43,6 +47,57 @@ def test_multi_frame_equals_oracle_frame(ids, exchange, partition):
             got = m.render(cam, p, partition)
             assert np.array_equal(got, want)
             assert m.stats().rays == rays
+    finally:
+        m.close()
+
+
+def test_multi_over_distinct_devices():
+    """Two or more GPUs: RCCL and peer copies between distinct devices, both partitions, against the
+    oracle.  Skipped on a one-GPU machine (no multi-GPU machine has run it yet)."""
+    import torch
+
+    n = min(torch.cuda.device_count(), 8)
+    if n < 2:
+        pytest.skip("needs at least two GPUs")
+    sc = c3_scene()
+    W, H, SPP, D = 200, 120, 2 * n + 1, 8
+    want, _, rays = O.trace_tile(sc, O.camera(*C3_CAM), W, H, SPP, D, O.RNG_COUNTER, seed=6)
+    cam, p = rtamd.make_camera(*C3_CAM), rtamd.params(W, H, SPP, D, seed=6)
+    for exchange in (rtamd.EXCHANGE_RCCL, rtamd.EXCHANGE_PEER_COPY, rtamd.EXCHANGE_AUTO):
+        m = rtamd.Multi(list(range(n)), exchange)
+        try:
+            m.set_scene(sc)
+            for partition in (rtamd.PARTITION_SAMPLES, rtamd.PARTITION_TILES):
+                for _ in range(3):
+                    m.reset_stats()
+                    assert np.array_equal(m.render(cam, p, partition), want), (exchange, partition)
+                    assert m.stats().rays == rays
+        finally:
+            m.close()
+
+
+def test_multi_shares_one_hierarchy_build_and_recovers_from_a_failed_frame():
+    """rt_multi_set_scene builds the hierarchy once and hands it to the other ranks' contexts (same
+    frames as with a build per rank); a frame that fails half way (a rank's call is refused) leaves
+    the object usable: the next frame is correct."""
+    sc = scenes.random_spheres(3000, grid_half=27)
+    cam = rtamd.make_camera(*C3_CAM)
+    p = rtamd.params(160, 90, 4, 8, seed=2)
+    ctx = rtamd.Context(0)
+    ctx.set_scene(sc)
+    want = ctx.render(cam, p)
+    ctx.close()
+    m = rtamd.Multi([0, 0, 0], rtamd.EXCHANGE_PEER_COPY)
+    try:
+        m.set_scene(sc)
+        assert np.array_equal(m.render(cam, p, rtamd.PARTITION_TILES), want)
+        L = rtamd.load()
+        buf = np.zeros((90, 160, 3), dtype=np.uint8)
+        bad = rtamd.params(160, 90, 4, 5000, seed=2)  # max_depth above the limit: every rank's trace call is refused
+        assert L.rt_multi_render(m._h, C.byref(cam), C.byref(bad), rtamd.PARTITION_SAMPLES, buf.ctypes.data) != 0
+        assert b"max_depth" in L.rt_multi_last_error(m._h)
+        for partition in (rtamd.PARTITION_SAMPLES, rtamd.PARTITION_TILES):
+            assert np.array_equal(m.render(cam, p, partition), want)
     finally:
         m.close()
 

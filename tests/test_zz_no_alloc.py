@@ -74,3 +74,58 @@ def test_static_entry_point_matches_render_device_twice_and_allocates_nothing():
         assert torch.equal(a, b) and int(a.count_nonzero()) > 0
     finally:
         ctx.close()
+
+
+def test_static_entry_point_under_graph_capture_and_across_contexts():
+    """The callers the entry point exists for.  (1) A stream under HIP graph capture: the call is captured
+    (it neither waits for nor records the context's ordering events there), the graph replays twice to the
+    bytes of rt_render_device, and a plain call on the same context afterwards still works.  (2) Two
+    contexts of one GPU calling on different streams without synchronising: the library orders calls on
+    the GPU's one scratch array, so both frames are right."""
+    import torch
+
+    ctx = rtamd.Context(0)
+    other = rtamd.Context(0)
+    try:
+        sc = np.fromfile(os.path.join(G, "scene_c3_500.bin"), dtype=rtamd.SPHERE_DTYPE)
+        ctx.set_scene(sc)
+        other.set_scene(sc)
+        cam = rtamd.make_camera(*scenes.RANDOM_SPHERES_CAMERA)
+        p, q = rtamd.params(320, 180, 6, 8, seed=41), rtamd.params(256, 144, 9, 8, seed=42)
+        want_p = torch.zeros(p.height * p.width * 3, dtype=torch.uint8, device="cuda")
+        want_q = torch.zeros(q.height * q.width * 3, dtype=torch.uint8, device="cuda")
+        ctx.render_device(cam, p, want_p.data_ptr())
+        ctx.render_device(cam, q, want_q.data_ptr())
+        torch.cuda.synchronize()
+        # (1) capture, replay twice
+        out = torch.zeros_like(want_p)
+        s = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+            ctx.render_device_static(cam, p, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for _ in range(2):
+            out.zero_()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want_p)
+        out.zero_()
+        ctx.render_device_static(cam, p, out.data_ptr())  # a plain call after the capture
+        torch.cuda.synchronize()
+        assert torch.equal(out, want_p)
+        # (2) two contexts, two streams, no synchronisation in between
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        out_q = torch.zeros_like(want_q)
+        for _ in range(3):
+            out.zero_()
+            out_q.zero_()
+            torch.cuda.synchronize()
+            ctx.render_device_static(cam, p, out.data_ptr(), stream=s1.cuda_stream)
+            other.render_device_static(cam, q, out_q.data_ptr(), stream=s2.cuda_stream)
+            ctx.render_device_static(cam, p, out.data_ptr(), stream=s2.cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(out, want_p) and torch.equal(out_q, want_q)
+    finally:
+        other.close()
+        ctx.close()
