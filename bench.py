@@ -68,8 +68,9 @@ FLOP_PER_NODE_VISIT = 60.0
 FLOP_PER_ROOT = 6.0           # negate, subtract, sqrt, divide, two range compares (Source/main.cpp:490-499)
 PEAK_FP32_TFLOPS = 157.3      # 256 CU x 128 FMA lanes x 2 flop x 2.4 GHz (matrix f32 = vector f32 on gfx950)
 PEAK_VALU_TLANEOPS = 78.6     # 256 CU x 4 SIMD x 32 lanes per clock x 2.4 GHz: one wave64 instruction per 2 cycles
-# rocprofv3 evidence of this build's `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`
-PROFILE_DIR = os.path.join("profiles", "r02_final")
+# rocprofv3 evidence of this build's `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`; the files
+# carry the fingerprint of the sources they were taken from, and are used only if it is this build's
+PROFILE_DIR = os.path.join("profiles", "r03_final")
 
 
 def cpu_baseline(scene):
@@ -97,22 +98,49 @@ def cpu_baseline(scene):
                         "port_value": rays / port_s / 1e6})
         except Exception as e:  # keep the port number
             out["reference_error"] = str(e)[:200]
-    # all host threads, column strips like TraceScene, one generator per strip
-    threads = max(1, min(16, os.cpu_count() or 1))
+    # All host threads, column strips like TraceScene (Source/main.cpp:7, 647-659), one generator per strip
+    # (the reference's shared generator is a data race).  One thread per CPU the host reports; the CPUs this
+    # job may actually use can be fewer (a GPU box gives one GPU's job a share of its host), so both are
+    # stated, and the sample is sized from the single-thread rate above for the share, not for the count.
+    host_cores = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores
+    try:
+        share = max(1, int(os.environ.get("OMP_NUM_THREADS", "") or usable))
+    except ValueError:
+        share = usable
+    threads = max(1, min(host_cores, W))
+    per_column_s = port_s / xs
+    columns = int(min(W, max(threads, 12.0 * min(share, usable, threads) / per_column_s)))
+    columns = max(threads, columns // threads * threads)  # whole strips
     import ctypes as C
     rgb = np.zeros((H, W, 3), dtype=np.uint8)
     r = C.c_uint64(0)
     t0 = time.time()
-    O.lib().orc_trace_scene_threads(scene.ctypes.data, len(scene), C.byref(ocam), W, H, SPP, DEPTH, W // 2 - 4 * threads,
-                                    8 * threads, threads, rgb.ctypes.data, C.byref(r))
+    O.lib().orc_trace_scene_threads(scene.ctypes.data, len(scene), C.byref(ocam), W, H, SPP, DEPTH, (W - columns) // 2,
+                                    columns, threads, rgb.ctypes.data, C.byref(r))
     mt_s = time.time() - t0
-    out["port_threads"] = {"value": r.value / mt_s / 1e6, "cores": threads,
-                           "sample": f"{8 * threads} centre columns, one strip and one generator per thread"}
+    out["port_threads"] = {"value": r.value / mt_s / 1e6, "unit": "Mrays/s", "threads": threads, "host_cores": host_cores,
+                           "cpus_in_affinity_mask": usable, "cpu_share_of_this_job": share, "seconds": mt_s,
+                           "sample": f"{columns} centre columns of the frame, all rows: one strip of {columns // threads} "
+                                     f"column(s) and one generator per thread, {threads} threads"}
     return out
 
 
+def profile_matches_build():
+    """True if the committed counter profile was taken from the sources this run's library was built from
+    (the profile carries their fingerprint), False if from others, None if there is no profile."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, PROFILE_DIR, "pmc_trace_kernel.json")))
+    except Exception:
+        return None
+    return prof.get("_build", {}).get("source_fingerprint") == rtamd.source_fingerprint()
+
+
 def load_profile(scan):
-    """Per-launch counters of `scan`'s trace kernel from the committed rocprofv3 passes, or None."""
+    """Per-launch counters of `scan`'s trace kernel from the committed rocprofv3 passes -- of THIS build --
+    or None."""
+    if not profile_matches_build():
+        return None
     path = os.path.join(ROOT, PROFILE_DIR, "pmc_trace_kernel.json")
     try:
         for name, rec in json.load(open(path)).items():
@@ -124,6 +152,8 @@ def load_profile(scan):
 
 
 def load_traffic(scan):
+    if not profile_matches_build():
+        return None
     try:
         return json.load(open(os.path.join(ROOT, PROFILE_DIR, "hbm_traffic.json")))["hbm_bytes_per_launch"].get(scan)
     except Exception:
@@ -148,6 +178,9 @@ def main():
     ap.add_argument("--exchange-alone", action="store_true",
                     help="N = 1: run the N > 1 path's pack / collective / unpack steps over a one-rank RCCL communicator "
                          "(exercises that path on a one-GPU machine; not the N = 1 measurement)")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="frames (steps) whose shares one trace launch carries (rt_accumulate_batch_device); 0 = 1 on one "
+                         "GPU, 4 on several, where a rank's share of a frame is small against a launch's drain")
     ap.add_argument("--scan", choices=sorted(SCANS), default="auto",
                     help="how rays find their candidate spheres (all give the same frame); auto = the library's choice")
     args = ap.parse_args()
@@ -195,22 +228,34 @@ def main():
         def __init__(self):
             self.events = None
 
-        def accumulate(self, params, sums):
+        def _timed(self, launch):
             if self.events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            tracer.accumulate(params, sums)
+            launch()
             if self.events is not None:
                 e1.record()
                 self.events.append((e0, e1))
+
+        def accumulate(self, params, sums):
+            self._timed(lambda: tracer.accumulate(params, sums))
+
+        def accumulate_batch(self, jobs):
+            self._timed(lambda: tracer.accumulate_batch(jobs))
 
         resolve = staticmethod(tracer.resolve)
         pack_tiles = staticmethod(tracer.pack_tiles)
         unpack_tiles = staticmethod(tracer.unpack_tiles)
 
     timed = TimedTracer()
-    pipe = dist_render.FramePipeline(timed, p, (W, H, total_spp), args.partition, rank, world, dist, torch, "cuda",
-                                     host_exchange=rehearsal, always_exchange=alone)
+    per_launch = args.frames_per_launch or (4 if world > 1 else 1)
+    per_launch = max(1, min(per_launch, rtamd.MAX_JOBS))
+
+    def make_pipe(frames_per_launch):
+        return dist_render.FramePipeline(timed, p, (W, H, total_spp), args.partition, rank, world, dist, torch, "cuda",
+                                         host_exchange=rehearsal, always_exchange=alone, frames_per_launch=frames_per_launch)
+
+    pipe = make_pipe(per_launch)
 
     def fence():
         torch.cuda.synchronize()
@@ -234,7 +279,8 @@ def main():
         pipe.finish()
         fence()
         seconds = time.perf_counter() - t0
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in timed.events])) if timed.events else 0.0
+        # kernel time per STEP: a launch may carry several steps' frames
+        kernel_ms = float(np.sum([a.elapsed_time(b) for a, b in timed.events])) / steps if timed.events else 0.0
         timed.events = None
         return seconds, kernel_ms, ctx.stats()
 
@@ -242,7 +288,17 @@ def main():
 
     # ---- second leg and counting launches (one GPU only: they are about the kernels, not the exchange)
     extra = world == 1 and not alone and not args.no_extra_legs and N_SPHERES <= 2000
-    list_leg = counted = None
+    list_leg = counted = batched_leg = None
+    if extra and per_launch == 1:
+        # the same frames, four to a launch: what the timed figure would be without the drain at every launch's end
+        pipe = make_pipe(4)
+        b_elapsed, b_kernel_ms, b_st = run_leg(args.steps, args.warmup)
+        batched_leg = {"frames_per_launch": 4, "steps": args.steps, "warmup": args.warmup,
+                       "ms_per_step": b_elapsed / args.steps * 1e3, "kernel_ms_per_step": b_kernel_ms,
+                       "value": b_st.rays / b_elapsed / 1e6, "unit": "Mrays/s",
+                       "note": "informational: the same frames traced four to a launch (rt_accumulate_batch_device), "
+                               "every frame zeroed, traced and resolved as in the timed leg"}
+        pipe = make_pipe(1)
     if extra:
         def count_work(filt):
             ctx.set_option(rtamd.OPT_FILTER, filt)
@@ -295,7 +351,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "weak",
+            "scaling": args.scaling if world > 1 else "none",
             "vs_baseline": None,
             "dtype": "f32",
             "data": ("synthetic (REHEARSAL over gloo: ranks share GPUs, not a measurement)" if rehearsal else
@@ -306,6 +362,7 @@ def main():
                 "max_depth": DEPTH, "partition": args.partition if world > 1 or alone else "none (one GPU)", "scan": scan,
                 "collective": collective,
                 "overlap": "exchange of frame k runs beside the tracing of frame k + 1" if world > 1 else "none",
+                "frames_per_launch": per_launch,
             },
             "rays_per_step": total_rays / args.steps,
             "lane_utilisation": total_rays / (64.0 * total_passes) if total_passes else None,
@@ -314,8 +371,11 @@ def main():
         }
 
         # ---- roofline of the timed kernel
-        prof = load_profile(scan) if args.workload == "c3" and world == 1 else None
-        roof = {"kernel": "trace_kernel, %s scan" % scan, "kernel_ms": kernel_ms}
+        prof = load_profile(scan) if args.workload == "c3" and world == 1 and per_launch == 1 else None
+        roof = {"kernel": "trace_kernel, %s scan" % scan, "kernel_ms": kernel_ms,
+                # the counters below are used only when they were taken from this build's sources
+                "profile": PROFILE_DIR, "profile_matches_build": profile_matches_build(),
+                "build_fingerprint": rtamd.source_fingerprint()}
         if scan in ("matrix", "vector", "exact"):
             # a list scan performs every one of the reference's tests: the survey's definition applies
             roof.update({"bound": "mfma" if scan == "matrix" else "valu",
@@ -325,7 +385,8 @@ def main():
                          "flop_per_unit": "25 flop per ray-sphere test x %d spheres per ray" % N_SPHERES})
         else:
             roof.update({"bound": "valu", "pipe": "vector ALU issue (the kernel executes no MFMA)",
-                         "achieved": None, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlaneop/s", "frac": None})
+                         "achieved": None, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlaneop/s", "frac": None,
+                         "basis": "no counter profile of this build (profile stale or absent): achieved and frac left null"})
             if prof and "SQ_INSTS_VALU" in prof and "derived" in prof and prof["derived"].get("valu_active_lane_share"):
                 d = prof["derived"]
                 lane_ops = prof["SQ_INSTS_VALU"] * 64.0 * d["valu_active_lane_share"]
@@ -344,7 +405,7 @@ def main():
                 })
             # the brute-force-equivalent rate: a speed-up figure, NOT a utilisation (the walk skips most tests)
             roof["reference_equivalent_tflops"] = ref_equiv
-        roof["traffic"] = load_traffic(scan) if args.workload == "c3" and world == 1 else None
+        roof["traffic"] = load_traffic(scan) if args.workload == "c3" and world == 1 and per_launch == 1 else None
         if counted and scan in counted:
             c = counted[scan]
             flop = (c["node_visits"] * FLOP_PER_NODE_VISIT + c["exact_tests"] * FLOP_PER_TEST +
@@ -379,6 +440,13 @@ def main():
             if counted and "matrix" in counted:
                 leg["executed_tests"] = counted["matrix"]
             roof["list_scan"] = leg
+            # the same leg's headline figures as scalars of their own (a reader that keeps only scalar keys keeps them)
+            roof["list_scan_frac"] = leg["frac"]
+            roof["list_scan_ms"] = l_kernel_ms
+            roof["list_scan_mrays"] = leg["value"]
+            roof["list_scan_tflops"] = a_list
+        if batched_leg:
+            line["batched_frames"] = batched_leg
         line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             line["cpu_baseline"] = cpu_baseline(scene)

@@ -62,6 +62,10 @@ class DeviceTracer:
     def accumulate(self, params, sums):
         self.ctx.accumulate_device(self.cam, params, sums.data_ptr(), stream=self._stream())
 
+    def accumulate_batch(self, jobs):
+        """jobs: [(params, sums tensor), ...] -- one launch for all of them (rt_accumulate_batch_device)."""
+        self.ctx.accumulate_batch_device([(self.cam, p, sums.data_ptr()) for p, sums in jobs], stream=self._stream())
+
     def resolve(self, sums, width, height, spp, rgb):
         self.ctx.resolve_device(sums.data_ptr(), width, height, spp, rgb.data_ptr(), stream=self._stream())
 
@@ -95,10 +99,17 @@ class FramePipeline:
     move device tensors, i.e. the gloo tests on one GPU).  always_exchange=True runs the pack /
     collective / unpack steps with world == 1 too (a one-rank communicator): the N > 1 code path on a
     one-GPU machine.
+
+    frames_per_launch > 1: a rank's shares of that many consecutive frames are traced by ONE launch
+    (tracer.accumulate_batch): a launch ends with the device draining its last paths (about 0.2 ms
+    whatever its size), which weighs on a rank's small share of a frame; in a launch of several frames
+    the waves go on with the next frame's work instead.  The frames of a group are exchanged one by one
+    behind the launch and completed, like single frames, while the next group is traced.  Slots are
+    then 2 x frames_per_launch.
     """
 
     def __init__(self, tracer, params, shape, partition, rank, world, dist, torch, device, slots=2,
-                 host_exchange=False, always_exchange=False):
+                 host_exchange=False, always_exchange=False, frames_per_launch=1):
         """`params` = rank_params(...) of this rank (None: nothing to trace); `shape` = (width, height,
         frame spp); `partition` = "samples" or "tiles"."""
         p = params
@@ -106,9 +117,14 @@ class FramePipeline:
         self.host_exchange = host_exchange
         self.exchange = world > 1 or always_exchange
         self.tiles = self.exchange and partition == "tiles"
+        self.group = max(1, int(frames_per_launch))
+        if self.group > 1:
+            slots = 2 * self.group
         self.slots = slots
         self.submitted = 0
         self.pending = None  # (slot, work handle) of the frame not yet completed
+        self.waiting = []    # slots of the group being collected (frames_per_launch > 1)
+        self.in_flight = []  # [(slot, work handle)] of the launched group not yet completed
         self.shape = tuple(shape)
         n = shape[0] * shape[1] * 3
         self.sums = [torch.zeros(n, dtype=torch.int32, device=device) for _ in range(slots)]
@@ -146,6 +162,8 @@ class FramePipeline:
     # -- frames
 
     def submit(self):
+        if self.group > 1:
+            return self._submit_grouped()
         s = self.submitted % self.slots
         if self.pending is not None and self.pending[0] == s:
             self._complete()  # the slot is still in flight (slots == 1)
@@ -166,6 +184,39 @@ class FramePipeline:
             self._complete(prev)
         return s
 
+    def _submit_grouped(self):
+        s = self.submitted % self.slots
+        self.waiting.append(s)
+        self.submitted += 1
+        if len(self.waiting) == self.group:
+            self._launch_group()
+        return s
+
+    def _launch_group(self):
+        """One trace launch for the collected frames, their exchanges started behind it; then the group
+        launched before is completed (its exchanges ran beside this launch's tracing)."""
+        group, self.waiting = self.waiting, []
+        if not group:
+            return
+        w, h, spp = self.shape
+        for s in group:
+            self.sums[s].zero_()
+        if self.p is not None:
+            self.tracer.accumulate_batch([(self.p, self.sums[s]) for s in group])
+        started = []
+        for s in group:
+            work = _Done()
+            if self.exchange:
+                if self.tiles:
+                    self.tracer.pack_tiles(self.sums[s], w, h, spp, self.rank, self.world, self.block[s])
+                    work, _ = self._gather_blocks(s)
+                else:
+                    work, _ = self._reduce_sums(s)
+            started.append((s, work))
+        prev, self.in_flight = self.in_flight, started
+        for item in prev:
+            self._complete(item)
+
     def _complete(self, item=None):
         if item is None:
             item, self.pending = self.pending, None
@@ -183,6 +234,11 @@ class FramePipeline:
 
     def finish(self):
         """Completes the frame still in flight; returns the slot of the last frame (rank 0's rgb[slot])."""
+        if self.group > 1:
+            self._launch_group()  # a last, shorter group
+            prev, self.in_flight = self.in_flight, []
+            for item in prev:
+                self._complete(item)
         self._complete()
         return (self.submitted - 1) % self.slots if self.submitted else None
 

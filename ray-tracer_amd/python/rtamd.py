@@ -195,6 +195,24 @@ FLAG_DIELECTRIC, FLAG_GAMMA2, FLAG_FLOAT_SHADING = 1, 2, 4
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)
 
 
+def source_fingerprint():
+    """sha256 over the library's sources (ray-tracer_amd/csrc, include/rt_mi355x.h), in sorted order: what
+    ties a committed hardware-counter profile to the build it was taken from."""
+    import glob
+    import hashlib
+
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    files = sorted(glob.glob(os.path.join(root, "ray-tracer_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(root, "ray-tracer_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(root, "ray-tracer_amd", "csrc", "*.cpp")) +
+                   [os.path.join(root, "ray-tracer_amd", "csrc", "Makefile"), os.path.join(root, "include", "rt_mi355x.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def params(width, height, spp, max_depth, seed=0, sample_begin=0, sample_count=0, tile_first=0, tile_stride=0,
            flags=0):
     return Params(width, height, spp, max_depth, seed, sample_begin, sample_count, tile_first, tile_stride, flags, 0)

@@ -37,6 +37,10 @@ class OracleTracer:
                                    want_sums=True)
             acc += s
 
+    def accumulate_batch(self, jobs):
+        for p, sums in jobs:
+            self.accumulate(p, sums)
+
     def resolve(self, sums, width, height, spp, rgb):
         q = sums.numpy().view(np.uint32) // spp
         rgb.numpy()[:] = np.minimum(q, 255).astype(np.uint8)
@@ -84,10 +88,18 @@ def _worker(rank, world, port, partition, out_path):
         pipe.submit()
     last = pipe.finish()
     dist.barrier()
+    # several frames per launch: five frames in groups of two (the last group is short), four slots
+    grouped = dist_render.FramePipeline(tracer, p, (W, H, SPP), partition, rank, world, dist, torch, "cpu",
+                                        frames_per_launch=2)
+    for _ in range(5):
+        grouped.submit()
+    last_grouped = grouped.finish()
+    dist.barrier()
     if rank == 0:
         np.save(out_path, rgb.numpy().reshape(H, W, 3))
         np.save(out_path + ".pipe.npy", torch.stack(pipe.rgb).numpy().reshape(2, H, W, 3))
-        assert last == 0
+        np.save(out_path + ".grouped.npy", torch.stack(grouped.rgb).numpy().reshape(4, H, W, 3))
+        assert last == 0 and last_grouped == 0 and grouped.slots == 4
     dist.destroy_process_group()
 
 
@@ -108,6 +120,8 @@ def test_two_rank_frame_equals_single_process_frame(tmp_path, partition):
     assert np.array_equal(got, want)
     piped = np.load(out + ".pipe.npy")
     assert np.array_equal(piped[0], want) and np.array_equal(piped[1], want)
+    grouped = np.load(out + ".grouped.npy")
+    assert all(np.array_equal(g, want) for g in grouped)
 
 
 def test_tile_blocks_cover_every_tile_once():

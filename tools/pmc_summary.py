@@ -14,6 +14,8 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ray-tracer_amd", "python"))
+
 NAMES = {", 3, ": "hierarchy scan", ", 2, ": "matrix scan", ", 1, ": "vector scan", ", 0, ": "exact scan"}
 N_SIMD = 1024.0  # 256 CUs x 4
 NOTE = ("per launch. kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs; SQ_WAVE_CYCLES counts quad-cycles summed over the chip: "
@@ -87,6 +89,20 @@ def main(src, dst):
                     "kernels named <.., 3, 0> are the timed hierarchy scan, <.., 2, 0> bench.py's list-scan leg, <.., N, 2> "
                     "the counting builds of its untimed launches; SQ_* summed over the chip, GRBM_GUI_ACTIVE summed over "
                     "the 8 XCDs; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them (separate passes)")
+    # what bench.py compares with the sources it runs from before it trusts these counters: the
+    # fingerprint tools/profile.sh took on the GPU box next to the counters, else this tree's
+    build = None
+    try:
+        build = json.load(open(os.path.join(src, "build.json")))
+    except Exception:
+        try:
+            import rtamd
+
+            build = {"source_fingerprint": rtamd.source_fingerprint(), "taken": "when the profile was summarised"}
+        except Exception as e:
+            build = {"error": str(e)[:200]}
+    out["_build"] = build
+    traffic["_build"] = build
     with open(os.path.join(dst, "pmc_trace_kernel.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, per trace_kernel launch of the bench frame. "

@@ -8,6 +8,8 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+# which sources these counters belong to (bench.py refuses a profile of another build)
+python3 -c "import sys, json; sys.path.insert(0, 'ray-tracer_amd/python'); import rtamd; print(json.dumps({'source_fingerprint': rtamd.source_fingerprint(), 'taken': 'on the GPU box, by tools/profile.sh'}))" > "$OUT/build.json" || exit 1
 
 # (the timing pass with bench.py's own default steps, so that the first launch under the profiler, which
 # takes a millisecond longer, weighs little in the --stats average)
