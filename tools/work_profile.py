@@ -26,6 +26,7 @@ torch.cuda.synchronize()
 st = ctx.stats()
 prof = ctx.work_profile()
 prof.pop("cycles", None)
+prof.pop("timeline", None)
 passes = prof["pass"][0]
 print(f"rays {st.rays}  wave passes {passes}  rays per pass {st.rays / passes:.1f}")
 print(f"{'section':14s} {'per pass':>9s} {'lanes on':>9s} {'lane-executions per ray':>24s}")
