@@ -158,7 +158,8 @@ def load():
     if hasattr(L, "rt_accumulate_batch_device"):  # absent from older builds kept for A/B timing (RTAMD_LIBRARY)
         L.rt_accumulate_batch_device.argtypes = [vp, C.POINTER(Job), u32, vp]
     L.rt_set_option.argtypes = [vp, i, C.c_int64]
-    L.rt_get_option.argtypes = [vp, i, C.POINTER(C.c_int64)]
+    if hasattr(L, "rt_get_option"):
+        L.rt_get_option.argtypes = [vp, i, C.POINTER(C.c_int64)]
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_reset_stats.argtypes = [vp]
     if hasattr(L, "rt_get_work_profile"):  # absent from older builds kept for A/B timing (RTAMD_LIBRARY)
