@@ -178,8 +178,11 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *par
  * call allocates and frees nothing (no hipMalloc, no hipFree).  Limits and rules:
  *   - width * height <= RT_STATIC_MAX_PIXELS, else RT_ERR_INVALID_ARGUMENT;
  *   - each GPU the library runs on holds its own copy of the array (24 MiB + 16 KiB) until the
- *     process ends, and ALL contexts on one GPU share it: calls that overlap in time on one GPU race
- *     (calls on one context are ordered by the library, whatever their streams);
+ *     process ends, and ALL contexts on one GPU share it.  The library puts these calls in order per
+ *     GPU, whatever context and stream they come through -- except on a stream under graph capture:
+ *     there the call is captured as it stands (kernels only; it neither waits for nor records the
+ *     library's ordering events), and a replay of the graph races with any other use of the array on
+ *     that GPU that overlaps it in time;
  *   - the scan's device data must exist already: rt_set_scene and rt_set_option put the hierarchy
  *     on the device when the options select it, so this holds unless an earlier error prevented it. */
 #define RT_STATIC_MAX_PIXELS (1u << 21) /* 2 097 152: 1920 x 1080 fits */
@@ -266,10 +269,12 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out);
  * The picture is bit-identical to rt_render's for any n and either partition.  `exchange` selects
  * the transport: RT_EXCHANGE_RCCL (ncclReduce / grouped ncclSend+ncclRecv; librccl is loaded with
  * dlopen by this call), RT_EXCHANGE_PEER_COPY (the first device adds the others' sums in place over
- * xGMI peer access, tile blocks are copied device to device), RT_EXCHANGE_AUTO (RCCL if it loads
- * and all ids are distinct, else peer copies; creation fails with RT_ERR_HIP when neither transport
- * exists between the first device and another one).  The same id may appear several times (ranks sharing
- * a device exchange by peer copies; meant for testing on one GPU).  At most 16 entries.
+ * xGMI peer access, tile blocks are copied device to device), RT_EXCHANGE_AUTO (peer copies where the
+ * first device can address every other one, else RCCL if it loads and all ids are distinct; creation
+ * fails with RT_ERR_HIP when neither transport exists between the first device and another one).  With
+ * one device RT_EXCHANGE_RCCL runs the same calls as with several (the rank reduces in place and sends
+ * its block to itself).  The same id may appear several times (ranks sharing a device exchange by peer
+ * copies; meant for testing on one GPU).  At most 16 entries.
  * Frames are double-buffered: rt_multi_render_device returns when the frame is enqueued, and the
  * exchange of one frame runs beside the tracing of the next. */
 typedef struct rt_multi rt_multi;
@@ -325,8 +330,12 @@ typedef enum rt_option {
     RT_OPT_DIRECT_ADD_SAMPLES = 10, /* calls (or cut chunks) of at most this many samples per pixel add every path's colour to the
                                      frame with atomics of its own instead of through per-chunk sums in LDS, so that a wave
                                      never waits for a chunk to drain (0..64, default 1, 0 = never).  Results do not depend on it. */
-    RT_OPT_COUNT_WORK = 9         /* 1: trace with the counting build, which fills rt_stats' node_visits, exact_tests and
+    RT_OPT_COUNT_WORK = 9,        /* 1: trace with the counting build, which fills rt_stats' node_visits, exact_tests and
                                      root_evaluations (slower; for measurement); 0 (default): those stay 0 */
+    RT_OPT_MAX_CHUNKS_PER_LAUNCH = 11 /* a launch's work queue counts its chunks in 31 bits: a call whose 8x8 tiles times
+                                     256-sample runs outnumber this (default and most 2^30 - 1) has its sample range traced
+                                     by several launches, one after the other.  Results do not depend on it; lowering it
+                                     exists to test that */
 } rt_option;
 
 int rt_set_option(rt_context *ctx, int option, int64_t value);

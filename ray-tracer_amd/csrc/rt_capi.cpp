@@ -53,6 +53,7 @@ struct rt_context {
     uint32_t subtiles_max = 4;     // work queue: tiles may be cut into this many strips of rows (1, 2 or 4)
     uint32_t chunks_per_wave = 32; // work queue: split tiles' samples until there are this many chunks per resident wave
     uint32_t direct_add_samples = 1; // RT_OPT_DIRECT_ADD_SAMPLES
+    uint32_t max_chunks = 0x3fffffffu; // RT_OPT_MAX_CHUNKS_PER_LAUNCH: beyond it a call's sample range goes in several launches
     bool count_work = false;       // RT_OPT_COUNT_WORK: launch the counting build of the trace kernel
     uint32_t bvh_auto_min = 13;    // automatic choice: hierarchy from this many spheres up (measured: it beats the
                                    // vector scan from 16 spheres; lists of up to 12 have a kernel of their own)
@@ -543,12 +544,12 @@ int enqueue_accumulate(rt_context *ctx, const rt_camera *cam, const rt_params *p
 {
     JobSpec js = { cam, *p, rg, d_sums };
     const uint32_t first = p->sample_begin, count = p->sample_count ? p->sample_count : p->spp;
-    // at most 2^30 chunks per launch at the finest cut (256 samples per chunk of a whole tile)
+    // at most max_chunks (2^30 - 1) chunks per launch, counted at the coarsest cut: whole tiles, 256 samples per chunk
     const uint64_t tiles = (uint64_t)((rg.w + kTileW - 1) / kTileW) * (uint64_t)((rg.h + kTileH - 1) / kTileH);
     const uint64_t segs = (count + kSegmentSamplesMax - 1u) / kSegmentSamplesMax;
-    if (tiles * segs <= 0x3fffffffull)
+    if (tiles * segs <= ctx->max_chunks)
         return enqueue_jobs(ctx, &js, 1u, stream, queue_heads, may_allocate, ordered);
-    const uint64_t segs_per_launch = std::max<uint64_t>(0x3fffffffull / std::max<uint64_t>(tiles, 1u), 1u);
+    const uint64_t segs_per_launch = std::max<uint64_t>(ctx->max_chunks / std::max<uint64_t>(tiles, 1u), 1u);
     const uint64_t step = segs_per_launch * kSegmentSamplesMax;
     for (uint64_t done = 0u; done < count; done += step) {
         js.p.sample_begin = first + (uint32_t)done;
@@ -1378,6 +1379,11 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_COUNT_WORK takes 0 or 1");
         ctx->count_work = value == 1;
         return RT_OK;
+    case RT_OPT_MAX_CHUNKS_PER_LAUNCH:
+        if (value < 1 || value > 0x3fffffff)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_MAX_CHUNKS_PER_LAUNCH takes 1..2^30-1");
+        ctx->max_chunks = (uint32_t)value;
+        return RT_OK;
     case RT_OPT_BVH_MIN_SPHERES:
         if (value < 1 || value > (1ll << 30))
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_MIN_SPHERES takes 1..2^30");
@@ -1416,6 +1422,7 @@ int rt_get_option(rt_context *ctx, int option, int64_t *value)
     case RT_OPT_SUBTILES: *value = ctx->subtiles_max; break;
     case RT_OPT_DIRECT_ADD_SAMPLES: *value = ctx->direct_add_samples; break;
     case RT_OPT_COUNT_WORK: *value = ctx->count_work ? 1 : 0; break;
+    case RT_OPT_MAX_CHUNKS_PER_LAUNCH: *value = ctx->max_chunks; break;
     default:
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option");
     }

@@ -30,7 +30,7 @@ def torch():
 
 ALL_OPTIONS = [rtamd.OPT_FILTER, rtamd.OPT_TILE_SPHERES, rtamd.OPT_WORKGROUPS_PER_CU, rtamd.OPT_BVH_LEAF_SPHERES,
                rtamd.OPT_BVH_MIN_SPHERES, rtamd.OPT_BVH_LDS_NODES, rtamd.OPT_BVH_SUSPEND_LANES, rtamd.OPT_CHUNKS_PER_WAVE,
-               rtamd.OPT_SUBTILES, rtamd.OPT_COUNT_WORK, rtamd.OPT_DIRECT_ADD_SAMPLES]
+               rtamd.OPT_SUBTILES, rtamd.OPT_COUNT_WORK, rtamd.OPT_DIRECT_ADD_SAMPLES, rtamd.OPT_MAX_CHUNKS_PER_LAUNCH]
 
 
 @pytest.fixture(scope="module")
@@ -588,6 +588,33 @@ def test_batched_jobs_add_what_separate_calls_add(ctx, torch, filt):
         # jobs with nothing to trace are skipped
         ctx.accumulate_batch_device([(cam_a, rtamd.params(61, 43, 9, 0, seed=77), bufs[0].data_ptr())])
         torch.cuda.synchronize()
+    finally:
+        restore_shipped_options(ctx)
+
+
+def test_a_call_too_large_for_one_work_queue_goes_in_several_launches(ctx, torch):
+    """A call whose tiles x 256-sample runs outnumber what a launch's queue can count has its sample
+    range traced by several launches (instead of being refused).  With the limit lowered to 40 chunks,
+    a 64 x 40 frame (40 tiles) of 700 samples takes three launches: same sums and ray count as the oracle's."""
+    sc = rtamd.default_scene()
+    ctx.set_scene(sc)
+    cam = rtamd.default_camera()
+    W, H, SPP, D = 64, 40, 700, 4
+    _, sums_o, rays_o = O.trace_tile(sc, O.default_camera(), W, H, SPP, D, O.RNG_COUNTER, seed=5, want_sums=True)
+    d_sums = torch.zeros(H * W * 3, dtype=torch.int32, device="cuda")
+    try:
+        for limit in (40, 100, 1 << 29):
+            ctx.set_option(rtamd.OPT_MAX_CHUNKS_PER_LAUNCH, limit)
+            d_sums.zero_()
+            ctx.reset_stats()
+            ctx.accumulate_device(cam, rtamd.params(W, H, SPP, D, seed=5), d_sums.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(d_sums.cpu().numpy().view(np.uint32).reshape(H, W, 3), sums_o), limit
+            assert ctx.stats().rays == rays_o
+        # the same through the entry points that render a frame
+        ctx.set_option(rtamd.OPT_MAX_CHUNKS_PER_LAUNCH, 40)
+        want, _, _ = O.trace_tile(sc, O.default_camera(), W, H, SPP, D, O.RNG_COUNTER, seed=5)
+        assert np.array_equal(ctx.render(cam, rtamd.params(W, H, SPP, D, seed=5)), want)
     finally:
         restore_shipped_options(ctx)
 
