@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="frames (steps) whose shares one trace launch carries (rt_accumulate_batch_device); 0 = 1 on one "
                          "GPU, 4 on several, where a rank's share of a frame is small against a launch's drain")
+    ap.add_argument("--batched-leg", action="store_true",
+                    help="N = 1: also time the same frames four to a launch (informational `batched_frames` entry; off by "
+                         "default so that every launch of the timed kernel in a profile of this command is one frame)")
     ap.add_argument("--scan", choices=sorted(SCANS), default="auto",
                     help="how rays find their candidate spheres (all give the same frame); auto = the library's choice")
     args = ap.parse_args()
@@ -289,7 +292,7 @@ def main():
     # ---- second leg and counting launches (one GPU only: they are about the kernels, not the exchange)
     extra = world == 1 and not alone and not args.no_extra_legs and N_SPHERES <= 2000
     list_leg = counted = batched_leg = None
-    if extra and per_launch == 1:
+    if extra and per_launch == 1 and args.batched_leg:
         # the same frames, four to a launch: what the timed figure would be without the drain at every launch's end
         pipe = make_pipe(4)
         b_elapsed, b_kernel_ms, b_st = run_leg(args.steps, args.warmup)
