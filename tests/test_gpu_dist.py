@@ -126,6 +126,16 @@ def _rccl_worker(rank, world, port, out_path):
         torch.cuda.synchronize()
         dist.barrier()
         frames.append(torch.stack(pipe.rgb).cpu().numpy().reshape(2, H, W, 3))
+        # the same with three frames to a launch: seven frames = two whole groups and a short one, six slots
+        grouped = dist_render.FramePipeline(tracer, p, (W, H, SPP), partition, rank, world, dist, torch, "cuda",
+                                            always_exchange=True, frames_per_launch=3)
+        for _ in range(7):
+            grouped.submit()
+        grouped.finish()
+        torch.cuda.synchronize()
+        dist.barrier()
+        for slot in range(grouped.slots):
+            assert torch.equal(grouped.rgb[slot], pipe.rgb[0]), (partition, slot)
     np.save(out_path, np.stack(frames))
     ctx.close()
     dist.destroy_process_group()
@@ -146,17 +156,20 @@ def test_exchange_path_over_a_one_rank_rccl_communicator(tmp_path):
             assert np.array_equal(got[part, slot], want)
 
 
-@pytest.mark.parametrize("partition", ["tiles", "samples"])
-def test_bench_exchange_path_alone_over_rccl(partition):
+@pytest.mark.parametrize("partition,per_launch,steps", [("tiles", 1, 2), ("samples", 1, 2), ("tiles", 2, 5), ("samples", 4, 5)])
+def test_bench_exchange_path_alone_over_rccl(partition, per_launch, steps):
+    """bench.py's N > 1 steps (pack, collective, unpack / reduce, resolve) over a one-rank RCCL communicator,
+    one frame per launch and several (whole groups and a last, shorter one)."""
     import json
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_PORT=str(_free_port()))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--exchange-alone",
-           "--partition", partition, "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", str(steps), "--warmup", "1", "--exchange-alone",
+           "--partition", partition, "--no-cpu-baseline", "--frames-per-launch", str(per_launch)]
     out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=280, cwd=root, env=env).stdout
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["rays_per_step"] == 301321686
+    assert line["n_gpus"] == 1 and line["rays_per_step"] == 301321686 and line["steps"] == steps
+    assert line["config"]["frames_per_launch"] == per_launch
     assert line["config"]["partition"] == partition and "not the N = 1 measurement" in line["data"]
     assert ("gather" if partition == "tiles" else "reduce") in line["config"]["collective"]
