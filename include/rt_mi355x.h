@@ -322,11 +322,12 @@ typedef enum rt_option {
     RT_OPT_BVH_SUSPEND_LANES = 6, /* a 64-lane wave stops walking the hierarchy when at most this many of its rays
                                      are still at it; they resume in the wave's next pass (0..63, 0 = never) */
     RT_OPT_CHUNKS_PER_WAVE = 7,   /* work queue granularity: a call whose 8x8-pixel tiles number fewer than this many
-                                     per resident wave cuts each tile into 2 or 4 strips of rows and then its samples
+                                     per resident wave cuts each tile into 2, 4 or 8 strips of rows and then its samples
                                      into segments, chunks of at least 256 paths; segments add into the frame with
                                      atomics (0..256, default 32, 0 = never cut, except that a chunk never holds more than 256 samples
                                      of a pixel).  Results do not depend on it. */
-    RT_OPT_SUBTILES = 8,          /* most strips of rows a tile is cut into before its samples are: 1, 2 or 4 (default) */
+    RT_OPT_SUBTILES = 8,          /* most strips of rows a tile is cut into before its samples are: 1, 2, 4 or 8 (default:
+                                     single rows; strips own their pixels and add into the frame with plain stores) */
     RT_OPT_DIRECT_ADD_SAMPLES = 10, /* calls (or cut chunks) of at most this many samples per pixel add every path's colour to the
                                      frame with atomics of its own instead of through per-chunk sums in LDS, so that a wave
                                      never waits for a chunk to drain (0..64, default 1, 0 = never).  Results do not depend on it. */

@@ -50,7 +50,7 @@ struct rt_context {
     int bvh_leaf_max = 0;          // RT_OPT_BVH_LEAF_SPHERES; 0 = by scene size (chosen_leaf_spheres())
     uint32_t bvh_suspend_lanes = 16;  // see RT_OPT_BVH_SUSPEND_LANES
     uint32_t bvh_lds_nodes_max = 512; // trees up to this many nodes (64 B each) are walked in LDS
-    uint32_t subtiles_max = 4;     // work queue: tiles may be cut into this many strips of rows (1, 2 or 4)
+    uint32_t subtiles_max = 8;     // work queue: tiles may be cut into this many strips of rows (1, 2, 4 or 8)
     uint32_t chunks_per_wave = 32; // work queue: split tiles' samples until there are this many chunks per resident wave
     uint32_t direct_add_samples = 1; // RT_OPT_DIRECT_ADD_SAMPLES
     uint32_t max_chunks = 0x3fffffffu; // RT_OPT_MAX_CHUNKS_PER_LAUNCH: beyond it a call's sample range goes in several launches
@@ -473,12 +473,24 @@ int enqueue_jobs(rt_context *ctx, const JobSpec *specs, uint32_t n, hipStream_t 
         // that the waves find the same granularity at every job's end)
         const uint64_t wanted = (uint64_t)ctx->chunks_per_wave * 4u * n_wg;
         uint64_t per_tile = (wanted + j.n_chunks - 1u) / j.n_chunks; // chunks wanted of each tile
-        if (per_tile >= 2u && ctx->subtiles_max >= 2u && j.sample_count >= 8u)
+        // Strips of rows first, and as many as leave a chunk kMinChunkPaths paths: strips own their pixels
+        // and flush with plain stores whatever their number (a tile's pixels are written once either way),
+        // and the finer the chunks, the more evenly a launch ends -- also where tiles abound (4K at 64 spp:
+        // 24.8 ms with two strips per tile, 24.1 with four).  Sample segments, which share pixels and flush
+        // with atomics (one counted write per addition), only for what is still missing.
+        constexpr uint32_t kMinChunkPaths = 512u;
+        if (ctx->chunks_per_wave != 0u)
+            while (j.subtiles * 2u <= ctx->subtiles_max && (uint64_t)(64u / (j.subtiles * 2u)) * j.sample_count >= kMinChunkPaths)
+                j.subtiles *= 2u;
+        // (small calls may go below that, down to 256 paths a chunk, to have enough chunks at all)
+        if (per_tile >= 2u && ctx->subtiles_max >= 2u && j.sample_count >= 8u && j.subtiles < 2u)
             j.subtiles = 2u;
-        if (per_tile >= 3u && ctx->subtiles_max >= 4u && j.sample_count >= 16u)
+        if (per_tile >= 3u && ctx->subtiles_max >= 4u && j.sample_count >= 16u && j.subtiles < 4u)
             j.subtiles = 4u;
+        if (per_tile >= 5u && ctx->subtiles_max >= 8u && j.sample_count >= 32u && j.subtiles < 8u)
+            j.subtiles = 8u;
         per_tile = (per_tile + j.subtiles - 1u) / j.subtiles;
-        const uint32_t min_segment = 4u * j.subtiles; // 256 paths on 64, 32 or 16 pixels
+        const uint32_t min_segment = 4u * j.subtiles; // 256 paths on 64, 32, 16 or 8 pixels
         uint32_t per = j.sample_count;
         if (per_tile >= 2u && j.sample_count >= 2u * min_segment) {
             per = (uint32_t)((j.sample_count + per_tile - 1u) / per_tile);
@@ -1365,8 +1377,8 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
         ctx->chunks_per_wave = (uint32_t)value;
         return RT_OK;
     case RT_OPT_SUBTILES:
-        if (value != 1 && value != 2 && value != 4)
-            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_SUBTILES takes 1, 2 or 4");
+        if (value != 1 && value != 2 && value != 4 && value != 8)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_SUBTILES takes 1, 2, 4 or 8");
         ctx->subtiles_max = (uint32_t)value;
         return RT_OK;
     case RT_OPT_DIRECT_ADD_SAMPLES:

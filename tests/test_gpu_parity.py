@@ -433,7 +433,7 @@ def test_split_sample_ranges_give_the_same_sums(ctx, torch, filt):
     d_sums = torch.zeros(H * W * 3, dtype=torch.int32, device="cuda")
     try:
         for per_wave, subtiles in ((0, 4), (1, 1), (16, 1), (32, 1), (256, 1), (1, 2), (32, 2), (256, 2), (1, 4), (16, 4),
-                                   (32, 4), (256, 4)):
+                                   (32, 4), (256, 4), (1, 8), (32, 8), (256, 8)):
             ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, per_wave)
             ctx.set_option(rtamd.OPT_SUBTILES, subtiles)
             d_sums.zero_()
@@ -510,7 +510,7 @@ def test_random_calls_do_not_depend_on_how_the_queue_cuts_them(ctx, torch):
                              tile_first=first, tile_stride=stride)
             ctx.set_option(rtamd.OPT_FILTER, int(rs.choice([rtamd.FILTER_AUTO, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_BVH])))
             out = []
-            for per_wave, subtiles in ((0, 4), (int(rs.choice([1, 16, 32, 256])), int(rs.choice([1, 2, 4])))):
+            for per_wave, subtiles in ((0, 4), (int(rs.choice([1, 16, 32, 256])), int(rs.choice([1, 2, 4, 8])))):
                 ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, per_wave)
                 ctx.set_option(rtamd.OPT_SUBTILES, subtiles)
                 d_sums = torch.full((H * W * 3,), 5, dtype=torch.int32, device="cuda")
@@ -570,7 +570,7 @@ def test_batched_jobs_add_what_separate_calls_add(ctx, torch, filt):
                                     O.RNG_COUNTER, seed=77, want_sums=True)
         assert np.array_equal(got[3].view(np.uint32).reshape(48, 80, 3), sums_o)
         # every cut of the work queue
-        for per_wave, subtiles in ((0, 4), (1, 1), (32, 2), (256, 4)):
+        for per_wave, subtiles in ((0, 4), (1, 1), (32, 2), (256, 4), (256, 8)):
             ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, per_wave)
             ctx.set_option(rtamd.OPT_SUBTILES, subtiles)
             for b in bufs + [shared]:
@@ -781,6 +781,7 @@ def test_full_size_frame_properties(ctx, torch):
     This is the frame bench.py times: it must run under the options a fresh context ships with."""
     assert {o: ctx.get_option(o) for o in ALL_OPTIONS} == ctx.shipped
     assert ctx.shipped[rtamd.OPT_CHUNKS_PER_WAVE] == 32 and ctx.shipped[rtamd.OPT_FILTER] == rtamd.FILTER_AUTO
+    assert ctx.shipped[rtamd.OPT_SUBTILES] == 8
     sc = c3_scene()
     ctx.set_scene(sc)
     cam = rtamd.make_camera(*C3_CAM)

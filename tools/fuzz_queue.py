@@ -26,7 +26,7 @@ for case in range(cases):
     p = rtamd.params(W, H, spp, int(rs.randint(1, 9)), seed=case, sample_begin=s0, sample_count=cnt, tile_first=first, tile_stride=stride)
     ctx.set_option(rtamd.OPT_FILTER, int(rs.choice([rtamd.FILTER_AUTO, rtamd.FILTER_CONSERVATIVE, rtamd.FILTER_MATRIX, rtamd.FILTER_BVH])))
     out = []
-    for per_wave, subtiles in ((0, 4), (int(rs.choice([1, 4, 16, 64, 256])), int(rs.choice([1, 2, 4])))):
+    for per_wave, subtiles in ((0, 4), (int(rs.choice([1, 4, 16, 64, 256])), int(rs.choice([1, 2, 4, 8])))):
         ctx.set_option(rtamd.OPT_CHUNKS_PER_WAVE, per_wave)
         ctx.set_option(rtamd.OPT_SUBTILES, subtiles)
         d = torch.full((H * W * 3,), 7, dtype=torch.int32, device="cuda")
