@@ -79,8 +79,11 @@ struct rt_context {
     size_t rows_bytes = 0;
     // rt_render_progressive: a second frame, a copy stream and "frame resolved" events, so that the
     // next pass is traced while the last one's frame travels to the host and the callback runs
-    uint8_t *d_rgb2 = nullptr;
+    uint8_t *d_rgb2 = nullptr;  // the frames of a group of passes after the first
     size_t rgb2_bytes = 0;
+    uint32_t *d_sums2 = nullptr; // and their sums
+    size_t sums2_bytes = 0;
+    uint32_t progressive_group = 0; // RT_OPT_PROGRESSIVE_PASSES_PER_LAUNCH; 0 = by the passes' size
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_resolved[2] = { nullptr, nullptr };
     void *d_io_in = nullptr;    // scratch for rt_intersect's rays
@@ -659,6 +662,7 @@ int rt_destroy(rt_context *ctx)
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
     if (ctx->h_rows) (void)hipHostFree(ctx->h_rows);
     if (ctx->d_rgb2) (void)hipFree(ctx->d_rgb2);
+    if (ctx->d_sums2) (void)hipFree(ctx->d_sums2);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (hipEvent_t e : ctx->ev_resolved)
         if (e) (void)hipEventDestroy(e);
@@ -1081,8 +1085,27 @@ int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params
     if (rg.w == 0 || rg.h == 0)
         return RT_OK;
     const bool pipelined = samples_per_pass < params->spp; // more than one pass
+    // Passes of few samples go several to a launch (the launch's tail, paths running out with the work queue
+    // dry, costs as much as 2 samples per pixel): each of the group's passes adds into a sums frame of
+    // its own, running totals are formed behind the launch, every pass's frame is resolved and they
+    // are delivered one after the other, in order, while the next group is traced.  The first pass
+    // goes alone, so that the first frame is not held back.
+    const size_t sums_frame = frame_bytes * sizeof(uint32_t);
+    uint32_t group = 1u;
     if (pipelined) {
-        st = ensure(ctx, (void **)&ctx->d_rgb2, &ctx->rgb2_bytes, frame_bytes);
+        group = ctx->progressive_group ? ctx->progressive_group : std::max(16u / samples_per_pass, 1u);
+        group = std::min(group, (uint32_t)kMaxJobs);
+        while (group > 1u && (uint64_t)(group - 1u) * sums_frame > (1ull << 30))
+            --group;
+        const uint64_t tiles = (uint64_t)((rg.w + kTileW - 1) / kTileW) * (uint64_t)((rg.h + kTileH - 1) / kTileH);
+        const uint64_t segs = (samples_per_pass + kSegmentSamplesMax - 1u) / kSegmentSamplesMax;
+        if (tiles * segs * group > ctx->max_chunks)
+            group = 1u; // (passes this large gain nothing from company; enqueue_accumulate cuts them up)
+    }
+    if (pipelined) {
+        st = ensure(ctx, (void **)&ctx->d_rgb2, &ctx->rgb2_bytes, frame_bytes * std::max(group - 1u, 1u));
+        if (st == RT_OK && group > 1u)
+            st = ensure(ctx, (void **)&ctx->d_sums2, &ctx->sums2_bytes, sums_frame * (group - 1u));
         if (st != RT_OK)
             return st;
         if (!ctx->copy_stream)
@@ -1095,48 +1118,103 @@ int rt_render_progressive(rt_context *ctx, const rt_camera *cam, const rt_params
     if (ctx->trace_enqueued) // the sums are shared scratch: behind their previous user, as in rt_render_device
         RT_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_trace, 0));
     const size_t row_bytes = (size_t)params->width * 3u * sizeof(uint32_t);
-    RT_HIP(ctx, hipMemsetAsync((uint8_t *)ctx->d_sums + (size_t)rg.y0 * row_bytes, 0, (size_t)rg.h * row_bytes, s));
-    // Pass k's frame is resolved into one of two device frames and fetched on the copy stream; pass
-    // k + 1 is enqueued before the host waits for that copy and calls back, so the device traces
-    // while the frame travels and the caller looks at it.  (A callback that stops the render does
-    // so one enqueued pass late: that pass runs, its samples are never shown.)
-    auto enqueue_pass = [&](uint32_t begin) -> int {
-        rt_params pass = *params;
-        pass.sample_begin = begin;
-        pass.sample_count = std::min(samples_per_pass, params->spp - begin);
-        return enqueue_accumulate(ctx, cam, &pass, rg, ctx->d_sums, s);
+    const size_t rows_off = (size_t)rg.y0 * row_bytes, rows_len = (size_t)rg.h * row_bytes;
+    RT_HIP(ctx, hipMemsetAsync((uint8_t *)ctx->d_sums + rows_off, 0, rows_len, s));
+    // sums frames: the running total lives in ring[total_at]; a group's pass j adds into ring[total_at + j]
+    uint32_t *ring[kMaxJobs];
+    uint8_t *frames[kMaxJobs];
+    for (uint32_t j = 0; j < group; ++j) {
+        ring[j] = j == 0u ? ctx->d_sums : (uint32_t *)((uint8_t *)ctx->d_sums2 + (size_t)(j - 1u) * sums_frame);
+        frames[j] = j == 0u ? ctx->d_rgb : ctx->d_rgb2 + (size_t)(j - 1u) * frame_bytes;
+    }
+    uint32_t total_at = 0u;
+    struct Group {
+        uint32_t first = 0u, passes = 0u; // samples before the group, its number of passes
     };
-    st = enqueue_pass(0u);
-    if (st != RT_OK)
-        return st;
-    uint32_t k = 0u;
-    for (uint32_t done = 0; done < params->spp; ++k) {
-        done += std::min(samples_per_pass, params->spp - done);
-        uint8_t *frame = (k & 1u) ? ctx->d_rgb2 : ctx->d_rgb;
-        ResolveArgs a;
-        a.sums = ctx->d_sums; a.rgb = frame;
-        a.width = params->width; a.height = params->height; a.spp_div = done; a.flags = params->flags;
-        a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
-        RT_HIP(ctx, launch_resolve(a, s));
+    // Traces the passes of `g` (one launch) on top of the running total.
+    auto enqueue_trace = [&](const Group &g) -> int {
+        if (g.passes == 1u) {
+            rt_params pass = *params;
+            pass.sample_begin = g.first;
+            pass.sample_count = std::min(samples_per_pass, params->spp - g.first);
+            return enqueue_accumulate(ctx, cam, &pass, rg, ring[total_at], s);
+        }
+        JobSpec specs[kMaxJobs];
+        for (uint32_t j = 0; j < g.passes; ++j) {
+            uint32_t *into = ring[(total_at + j) % group];
+            if (j > 0u)
+                RT_HIP(ctx, hipMemsetAsync((uint8_t *)into + rows_off, 0, rows_len, s));
+            specs[j] = { cam, *params, rg, into };
+            specs[j].p.sample_begin = g.first + j * samples_per_pass;
+            specs[j].p.sample_count = std::min(samples_per_pass, params->spp - specs[j].p.sample_begin);
+        }
+        return enqueue_jobs(ctx, specs, g.passes, s);
+    };
+    // Behind the trace: running totals pass by pass, each resolved into its frame.
+    auto enqueue_frames = [&](const Group &g) -> int {
+        uint32_t done = g.first;
+        for (uint32_t j = 0; j < g.passes; ++j) {
+            uint32_t *sums = ring[(total_at + j) % group];
+            if (j > 0u) {
+                AddArgs add;
+                memset(&add, 0, sizeof add);
+                add.dst = sums + rows_off / sizeof(uint32_t);
+                add.src[0] = ring[(total_at + j - 1u) % group] + rows_off / sizeof(uint32_t);
+                add.n_src = 1u;
+                add.count = rows_len / sizeof(uint32_t);
+                RT_HIP(ctx, launch_add_sums(add, s));
+            }
+            done += std::min(samples_per_pass, params->spp - done);
+            ResolveArgs a;
+            a.sums = sums; a.rgb = frames[j];
+            a.width = params->width; a.height = params->height; a.spp_div = done; a.flags = params->flags;
+            a.x0 = rg.x0; a.y0 = rg.y0; a.w = rg.w; a.h = rg.h;
+            RT_HIP(ctx, launch_resolve(a, s));
+        }
+        total_at = (total_at + g.passes - 1u) % group;
+        if (pipelined)
+            RT_HIP(ctx, hipEventRecord(ctx->ev_resolved[0], s));
+        RT_HIP(ctx, hipEventRecord(ctx->ev_trace, s));
+        return RT_OK;
+    };
+    auto next_group = [&](const Group &g, uint32_t size) {
+        Group n;
+        n.first = std::min<uint64_t>((uint64_t)g.first + (uint64_t)g.passes * samples_per_pass, params->spp);
+        const uint32_t left = (params->spp - n.first + samples_per_pass - 1u) / samples_per_pass;
+        n.passes = std::min(size, left);
+        return n;
+    };
+    // The group in hand is traced and resolved; the next one is traced while the host fetches the
+    // frames of the one in hand and calls back, and resolved (into the same frames) afterwards.
+    // (A callback that stops the render does so one enqueued group late: that group runs, its
+    // samples are never shown.)
+    Group cur;
+    cur.passes = 1u;
+    st = enqueue_trace(cur);
+    if (st == RT_OK)
+        st = enqueue_frames(cur);
+    bool stop = false;
+    while (st == RT_OK && !stop && cur.passes != 0u) {
+        const Group next = next_group(cur, group);
         hipStream_t cs = s;
         if (pipelined) {
             cs = ctx->copy_stream;
-            RT_HIP(ctx, hipEventRecord(ctx->ev_resolved[k & 1u], s));
-            RT_HIP(ctx, hipStreamWaitEvent(cs, ctx->ev_resolved[k & 1u], 0));
-            if (done < params->spp) {
-                st = enqueue_pass(done);
-                if (st != RT_OK)
-                    break;
-            }
+            RT_HIP(ctx, hipStreamWaitEvent(cs, ctx->ev_resolved[0], 0));
+            if (next.passes != 0u)
+                st = enqueue_trace(next);
         }
-        RT_HIP(ctx, hipEventRecord(ctx->ev_trace, s));
-        st = copy_region_to_host(ctx, rgb, frame, params->width, rg, cs);
-        if (st != RT_OK)
-            break;
-        if (progress && progress(user, done, params->spp) != 0)
-            break;
+        uint32_t done = cur.first;
+        for (uint32_t j = 0; st == RT_OK && !stop && j < cur.passes; ++j) {
+            done += std::min(samples_per_pass, params->spp - done);
+            st = copy_region_to_host(ctx, rgb, frames[j], params->width, rg, cs);
+            if (st == RT_OK && progress && progress(user, done, params->spp) != 0)
+                stop = true;
+        }
+        if (st == RT_OK && !stop && next.passes != 0u)
+            st = enqueue_frames(next);
+        cur = next;
     }
-    if (pipelined) // a pass enqueued ahead of a stop, or of a failure
+    if (pipelined) // a group enqueued ahead of a stop, or of a failure
         RT_HIP(ctx, hipStreamSynchronize(s));
     if (st != RT_OK)
         return st;
@@ -1396,6 +1474,11 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_MAX_CHUNKS_PER_LAUNCH takes 1..2^30-1");
         ctx->max_chunks = (uint32_t)value;
         return RT_OK;
+    case RT_OPT_PROGRESSIVE_PASSES_PER_LAUNCH:
+        if (value < 0 || value > (int64_t)kMaxJobs)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_PROGRESSIVE_PASSES_PER_LAUNCH takes 0..8");
+        ctx->progressive_group = (uint32_t)value;
+        return RT_OK;
     case RT_OPT_BVH_MIN_SPHERES:
         if (value < 1 || value > (1ll << 30))
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_MIN_SPHERES takes 1..2^30");
@@ -1435,6 +1518,7 @@ int rt_get_option(rt_context *ctx, int option, int64_t *value)
     case RT_OPT_DIRECT_ADD_SAMPLES: *value = ctx->direct_add_samples; break;
     case RT_OPT_COUNT_WORK: *value = ctx->count_work ? 1 : 0; break;
     case RT_OPT_MAX_CHUNKS_PER_LAUNCH: *value = ctx->max_chunks; break;
+    case RT_OPT_PROGRESSIVE_PASSES_PER_LAUNCH: *value = ctx->progressive_group; break;
     default:
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option");
     }

@@ -25,6 +25,7 @@ OPT_SUBTILES = 8
 OPT_COUNT_WORK = 9
 OPT_DIRECT_ADD_SAMPLES = 10
 OPT_MAX_CHUNKS_PER_LAUNCH = 11
+OPT_PROGRESSIVE_PASSES_PER_LAUNCH = 12
 FILTER_AUTO, FILTER_EXACT, FILTER_CONSERVATIVE, FILTER_MATRIX, FILTER_BVH = -1, 0, 1, 2, 3
 
 # every symbol include/rt_mi355x.h declares

@@ -97,6 +97,38 @@ def test_progressive_passes_and_final_frame(ctx):
         assert np.array_equal(img, want)
 
 
+@pytest.mark.parametrize("per_launch", [0, 1, 3, 8])
+def test_progressive_small_passes_share_launches(ctx, per_launch):
+    """Passes of one or two samples are traced several to a launch (after the first, which goes alone): every
+    pass's frame is still delivered, in order, and is the average of the samples so far; a stop in the middle
+    of a launch's frames leaves the frame of the pass that asked for it."""
+    sc = c3_scene()
+    ctx.set_scene(sc)
+    cam, W, H, spp, depth = rtamd.make_camera(*C3_CAM), 72, 40, 13, 8
+    p = rtamd.params(W, H, spp, depth, seed=6)
+    ctx.set_option(rtamd.OPT_PROGRESSIVE_PASSES_PER_LAUNCH, per_launch)
+    try:
+        seen = []
+        final = ctx.render_progressive(cam, p, 1, lambda d, t, rgb: seen.append((d, rgb.copy())) and False)
+        assert [d for d, _ in seen] == list(range(1, spp + 1))
+        assert np.array_equal(final, ctx.render(cam, p))
+        for done, img in seen:
+            want, _, _ = O.trace_tile(sc, O.camera(*C3_CAM), W, H, done, depth, O.RNG_COUNTER, seed=6, s0=0, s1=done)
+            assert np.array_equal(img, want), done
+        # passes of two samples (the last one of one), a tile narrower than the frame, a stop at the sixth sample
+        tile = (9, 5, 40, 30)
+        calls = []
+        img = ctx.render_progressive(cam, p, 2, lambda d, t, rgb: calls.append(d) or d >= 6, tile=tile, fill=3)
+        assert calls == [2, 4, 6]
+        want = np.full((H, W, 3), 3, dtype=np.uint8)
+        O.trace_tile(sc, O.camera(*C3_CAM), W, H, 6, depth, O.RNG_COUNTER, seed=6, s0=0, s1=6, tile=tile, rgb=want)
+        assert np.array_equal(img, want)
+        # and the context's other calls are not disturbed by what the stopped call had enqueued
+        assert np.array_equal(ctx.render(cam, p), final)
+    finally:
+        ctx.set_option(rtamd.OPT_PROGRESSIVE_PASSES_PER_LAUNCH, 0)
+
+
 def test_progressive_early_stop_tile_and_errors(ctx):
     sc = rtamd.default_scene()
     ctx.set_scene(sc)

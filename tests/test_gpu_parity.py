@@ -30,7 +30,8 @@ def torch():
 
 ALL_OPTIONS = [rtamd.OPT_FILTER, rtamd.OPT_TILE_SPHERES, rtamd.OPT_WORKGROUPS_PER_CU, rtamd.OPT_BVH_LEAF_SPHERES,
                rtamd.OPT_BVH_MIN_SPHERES, rtamd.OPT_BVH_LDS_NODES, rtamd.OPT_BVH_SUSPEND_LANES, rtamd.OPT_CHUNKS_PER_WAVE,
-               rtamd.OPT_SUBTILES, rtamd.OPT_COUNT_WORK, rtamd.OPT_DIRECT_ADD_SAMPLES, rtamd.OPT_MAX_CHUNKS_PER_LAUNCH]
+               rtamd.OPT_SUBTILES, rtamd.OPT_COUNT_WORK, rtamd.OPT_DIRECT_ADD_SAMPLES, rtamd.OPT_MAX_CHUNKS_PER_LAUNCH,
+               rtamd.OPT_PROGRESSIVE_PASSES_PER_LAUNCH]
 
 
 @pytest.fixture(scope="module")

@@ -42,9 +42,15 @@ rgb[:] = 0
 ms = wall(strips)
 print(f"rt_render, four column strips one after the other: {ms:7.2f} ms, frame {'==' if np.array_equal(rgb, whole) else '!='} the whole call's",
       flush=True)
-for per_pass in (16, 4, 1):
-    ms = wall(lambda: ctx.render_progressive(cam, p, per_pass, lambda d, t, img: False, rgb=rgb))
-    same = np.array_equal(rgb, whole)
-    print(f"rt_render_progressive, {per_pass:2d} spp per pass ({SPP // per_pass} passes): {ms:7.2f} ms, "
-          f"{ms / (SPP // per_pass):6.3f} ms per pass, final frame {'==' if same else '!='} rt_render's", flush=True)
+import torch
+
+pinned = torch.empty((H, W, 3), dtype=torch.uint8, pin_memory=True).numpy()  # the caller's frame in pinned host memory
+for per_launch, frame in ((1, rgb), (0, rgb), (1, pinned), (0, pinned)):  # every pass a launch of its own / small passes share launches
+    ctx.set_option(rtamd.OPT_PROGRESSIVE_PASSES_PER_LAUNCH, per_launch)
+    for per_pass in (16, 4, 1):
+        ms = wall(lambda: ctx.render_progressive(cam, p, per_pass, lambda d, t, img: False, rgb=frame))
+        same = np.array_equal(frame, whole)
+        print(f"rt_render_progressive, {per_pass:2d} spp per pass ({SPP // per_pass} passes), "
+              f"{'one pass' if per_launch else 'up to 16 spp'} per launch, {'pinned' if frame is pinned else 'pageable'} frame: {ms:7.2f} ms, "
+              f"{ms / (SPP // per_pass):6.3f} ms per pass, final frame {'==' if same else '!='} rt_render's", flush=True)
 ctx.close()
