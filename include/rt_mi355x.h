@@ -279,7 +279,7 @@ int rt_intersect(rt_context *ctx, const float *rays, uint32_t n, void *out);
  * its block to itself).  The same id may appear several times (ranks sharing a device exchange by peer
  * copies; meant for testing on one GPU).  At most 16 entries.
  * Frames are double-buffered: rt_multi_render_device returns when the frame is enqueued, and the
- * exchange of one frame runs beside the tracing of the next. */
+ * exchange of one frame (or of one call's frames) runs beside the tracing of the next. */
 typedef struct rt_multi rt_multi;
 enum { RT_PARTITION_SAMPLES = 0, RT_PARTITION_TILES = 1 };
 enum { RT_EXCHANGE_AUTO = 0, RT_EXCHANGE_RCCL = 1, RT_EXCHANGE_PEER_COPY = 2 };
@@ -298,6 +298,14 @@ int rt_multi_render(rt_multi *multi, const rt_camera *cam, const rt_params *para
  * calls; rt_multi_synchronize waits for all of them). */
 int rt_multi_render_device(rt_multi *multi, const rt_camera *cam, const rt_params *params, int partition,
                            uint8_t *d_rgb);
+/* `n_frames` (<= RT_MAX_JOBS) frames in one call: cams[f], params[f] -> d_rgb[f] (first device's memory),
+ * the same pictures as n_frames calls of rt_multi_render_device.  Every device traces its shares of all
+ * the frames in ONE launch (rt_accumulate_batch_device: a device's share of a frame is small, and the
+ * end of a launch weighs on it), then the frames are exchanged and finished one by one.  The frames
+ * must share seed and flags, as the jobs of one launch do; their sizes may differ.  Only enqueues.
+ * Stands where a host would call TraceScene (Source/main.cpp:647-659) once per frame of a sequence. */
+int rt_multi_render_frames_device(rt_multi *multi, const rt_camera *cams, const rt_params *params, uint32_t n_frames,
+                                  int partition, uint8_t *const *d_rgb);
 int rt_multi_synchronize(rt_multi *multi);
 int rt_multi_get_stats(rt_multi *multi, rt_stats *stats);        /* counters summed over the devices */
 int rt_multi_reset_stats(rt_multi *multi);

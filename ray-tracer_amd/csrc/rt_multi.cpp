@@ -28,6 +28,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -39,7 +40,9 @@ using namespace rtamd;
 namespace {
 
 constexpr uint32_t kMaxRanks = 16; // also the add kernel's operand limit
-constexpr int kSlots = 2;
+// Buffer sets per rank: a call of g frames takes g of the first max(2, 2g), in rotation, so that two
+// calls' worth of frames can be in flight.  Only the sets a multi-device object has used exist.
+constexpr int kSlots = 2 * RT_MAX_JOBS;
 
 // The handful of RCCL entry points used, resolved at run time: a process that never asks for a
 // multi-device exchange never loads the library.
@@ -92,11 +95,11 @@ struct Rank {
     int device = 0;
     rt_context *ctx = nullptr;
     hipStream_t compute = nullptr, comm = nullptr;
-    uint32_t *sums[kSlots] = { nullptr, nullptr };
-    uint8_t *block[kSlots] = { nullptr, nullptr }; // ranks >= 1: this rank's tile block
-    hipEvent_t traced[kSlots] = { nullptr, nullptr };    // the rank's share of the slot's frame is in its buffers
-    hipEvent_t exchanged[kSlots] = { nullptr, nullptr }; // ... and has left them again
-    bool exchanged_valid[kSlots] = { false, false };
+    uint32_t *sums[kSlots] = {};
+    uint8_t *block[kSlots] = {}; // ranks >= 1: this rank's tile block
+    hipEvent_t traced[kSlots] = {};    // the rank's share of the slot's frame is in its buffers
+    hipEvent_t exchanged[kSlots] = {}; // ... and has left them again
+    bool exchanged_valid[kSlots] = {};
     ncclComm_t nccl = nullptr;
 };
 
@@ -122,7 +125,8 @@ struct rt_multi {
     RcclApi rccl;
     size_t sums_bytes = 0;   // per slot and rank, as allocated
     size_t block_bytes = 0;  // per slot and rank, as allocated
-    uint8_t *blocks[kSlots] = { nullptr, nullptr }; // first device: gather buffer, n ranks x block_bytes
+    int n_slots = 0;         // buffer sets allocated
+    uint8_t *blocks[kSlots] = {}; // first device: gather buffer, n ranks x block_bytes
     uint8_t *d_rgb = nullptr; // first device: frame of rt_multi_render
     size_t rgb_bytes = 0;
     uint64_t frames = 0;
@@ -182,24 +186,30 @@ void free_buffers(rt_multi *m)
         }
     }
     m->sums_bytes = m->block_bytes = 0;
+    m->n_slots = 0;
 }
 
-// Frame buffers of every rank, grown when a larger frame comes (after all enqueued work is done).
-int ensure_buffers(rt_multi *m, size_t sums_bytes, size_t block_bytes)
+// `n_slots` frame buffer sets of every rank, grown when a larger frame or a longer call comes (after all
+// enqueued work is done).
+int ensure_buffers(rt_multi *m, size_t sums_bytes, size_t block_bytes, int n_slots)
 {
-    if (m->sums_bytes >= sums_bytes && m->block_bytes >= block_bytes)
+    if (m->sums_bytes >= sums_bytes && m->block_bytes >= block_bytes && m->n_slots >= n_slots)
         return RT_OK;
+    sums_bytes = std::max(sums_bytes, m->sums_bytes);
+    block_bytes = std::max(block_bytes, m->block_bytes);
+    n_slots = std::max(n_slots, m->n_slots);
     for (Rank &r : m->ranks) {
         RTM_HIP(m, hipSetDevice(r.device));
         RTM_HIP(m, hipDeviceSynchronize());
-        r.exchanged_valid[0] = r.exchanged_valid[1] = false;
+        for (bool &v : r.exchanged_valid)
+            v = false;
     }
     free_buffers(m);
     const size_t n = m->ranks.size();
     for (size_t i = 0; i < n; ++i) {
         Rank &r = m->ranks[i];
         RTM_HIP(m, hipSetDevice(r.device));
-        for (int s = 0; s < kSlots; ++s) {
+        for (int s = 0; s < n_slots; ++s) {
             if (hipMalloc((void **)&r.sums[s], sums_bytes) != hipSuccess)
                 return fail(m, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for a rank's sums");
             // (over RCCL the first rank sends its block like every other; with peer copies it packs
@@ -209,12 +219,13 @@ int ensure_buffers(rt_multi *m, size_t sums_bytes, size_t block_bytes)
         }
     }
     RTM_HIP(m, hipSetDevice(m->ranks[0].device));
-    for (int s = 0; s < kSlots; ++s) {
+    for (int s = 0; s < n_slots; ++s) {
         if (hipMalloc((void **)&m->blocks[s], n * block_bytes) != hipSuccess)
             return fail(m, RT_ERR_OUT_OF_MEMORY, "hipMalloc failed for the gather buffer");
     }
     m->sums_bytes = sums_bytes;
     m->block_bytes = block_bytes;
+    m->n_slots = n_slots;
     return RT_OK;
 }
 
@@ -400,7 +411,31 @@ int rt_multi_synchronize(rt_multi *m)
 
 namespace {
 
-int enqueue_frame(rt_multi *m, const rt_camera *cam, const rt_params *params, int partition, uint8_t *d_rgb);
+int enqueue_frames(rt_multi *m, const rt_camera *cams, const rt_params *params, uint32_t n_frames, int partition,
+                   uint8_t *const *d_rgb);
+
+// Enqueues; on an error part of the call may be enqueued on some devices and not on others: wait for
+// what is, and forget every slot's "left the buffers" event, so that the next frame starts from idle
+// devices instead of on top of buffers something may still read.  (The error message is kept.)
+int enqueue_or_drain(rt_multi *m, const rt_camera *cams, const rt_params *params, uint32_t n_frames, int partition,
+                     uint8_t *const *d_rgb)
+{
+    const int st = enqueue_frames(m, cams, params, n_frames, partition, d_rgb);
+    if (st != RT_OK) {
+        const std::string why = m->error;
+        for (Rank &r : m->ranks) {
+            if (hipSetDevice(r.device) == hipSuccess) {
+                (void)hipStreamSynchronize(r.compute);
+                (void)hipStreamSynchronize(r.comm);
+            }
+            for (bool &v : r.exchanged_valid)
+                v = false;
+        }
+        (void)hipGetLastError();
+        m->error = why;
+    }
+    return st;
+}
 
 } // namespace
 
@@ -412,150 +447,190 @@ int rt_multi_render_device(rt_multi *m, const rt_camera *cam, const rt_params *p
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::recursive_mutex> lock(m->mtx);
     DeviceGuard guard;
-    const int st = enqueue_frame(m, cam, params, partition, d_rgb);
-    if (st != RT_OK) {
-        // Part of the frame may be enqueued on some devices and not on others: wait for what is, and
-        // forget both slots' "left the buffers" events, so that the next frame starts from idle
-        // devices instead of on top of buffers something may still read.  (The error message is kept.)
-        const std::string why = m->error;
-        for (Rank &r : m->ranks) {
-            if (hipSetDevice(r.device) == hipSuccess) {
-                (void)hipStreamSynchronize(r.compute);
-                (void)hipStreamSynchronize(r.comm);
-            }
-            r.exchanged_valid[0] = r.exchanged_valid[1] = false;
-        }
-        (void)hipGetLastError();
-        m->error = why;
-    }
-    return st;
+    return enqueue_or_drain(m, cam, params, 1u, partition, &d_rgb);
+}
+
+int rt_multi_render_frames_device(rt_multi *m, const rt_camera *cams, const rt_params *params, uint32_t n_frames,
+                                  int partition, uint8_t *const *d_rgb)
+{
+    if (!m)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lock(m->mtx);
+    if (n_frames == 0u)
+        return RT_OK;
+    if (n_frames > RT_MAX_JOBS)
+        return fail(m, RT_ERR_INVALID_ARGUMENT, "more than RT_MAX_JOBS frames in one call");
+    DeviceGuard guard;
+    return enqueue_or_drain(m, cams, params, n_frames, partition, d_rgb);
 }
 
 } // extern "C"
 
 namespace {
 
-int enqueue_frame(rt_multi *m, const rt_camera *cam, const rt_params *params, int partition, uint8_t *d_rgb)
+// The frames of one call: every rank traces its shares of all of them in ONE launch (the launch's end,
+// paths running out with the work queue dry, is paid once instead of per frame), then the frames are
+// exchanged and finished one by one.
+int enqueue_frames(rt_multi *m, const rt_camera *cams, const rt_params *params, uint32_t n_frames, int partition,
+                   uint8_t *const *d_rgb)
 {
-    if (!cam || !params || !d_rgb)
+    if (!cams || !params || !d_rgb)
         return fail(m, RT_ERR_INVALID_ARGUMENT, "null camera, params or d_rgb");
     if (partition != RT_PARTITION_SAMPLES && partition != RT_PARTITION_TILES)
         return fail(m, RT_ERR_INVALID_ARGUMENT, "partition must be RT_PARTITION_SAMPLES or RT_PARTITION_TILES");
-    if (params->sample_begin || params->sample_count || params->tile_first || params->tile_stride)
-        return fail(m, RT_ERR_INVALID_ARGUMENT, "rt_multi_render splits the frame itself: sample_* and tile_* must be 0");
-    if (params->width == 0 || params->height == 0 || params->spp == 0 ||
-        (uint64_t)params->width * params->height > (1ull << 30))
-        return fail(m, RT_ERR_INVALID_ARGUMENT, "bad frame size or spp");
     const uint32_t n = (uint32_t)m->ranks.size();
-    const uint32_t W = params->width, H = params->height;
-    const size_t count = (size_t)W * H * 3u;
-    const size_t bb = (size_t)rt_tile_block_bytes(W, H, 0u, n); // every rank's block padded to the first's
-    int st = ensure_buffers(m, count * sizeof(uint32_t), bb);
+    size_t sums_bytes = 0u, bb_max = 0u;
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        const rt_params &p = params[f];
+        if (!d_rgb[f])
+            return fail(m, RT_ERR_INVALID_ARGUMENT, "null camera, params or d_rgb");
+        if (p.sample_begin || p.sample_count || p.tile_first || p.tile_stride)
+            return fail(m, RT_ERR_INVALID_ARGUMENT, "rt_multi_render splits the frame itself: sample_* and tile_* must be 0");
+        if (p.width == 0 || p.height == 0 || p.spp == 0 || (uint64_t)p.width * p.height > (1ull << 30))
+            return fail(m, RT_ERR_INVALID_ARGUMENT, "bad frame size or spp");
+        sums_bytes = std::max(sums_bytes, (size_t)p.width * p.height * 3u * sizeof(uint32_t));
+        bb_max = std::max(bb_max, (size_t)rt_tile_block_bytes(p.width, p.height, 0u, n)); // every rank's block padded to the first's
+    }
+    const int ring = std::max(2, 2 * (int)n_frames);
+    int st = ensure_buffers(m, sums_bytes, bb_max, ring);
     if (st != RT_OK)
         return st;
-    const int slot = (int)(m->frames % kSlots);
+    int slots[RT_MAX_JOBS];
+    for (uint32_t f = 0; f < n_frames; ++f)
+        slots[f] = (int)((m->frames + f) % (uint64_t)ring);
     Rank &root = m->ranks[0];
     const bool tiles = partition == RT_PARTITION_TILES;
 
-    // ---- every rank: zero, trace its share, (tiles) divide and pack -- on its compute stream
+    // ---- every rank: zero, trace its shares, (tiles) divide and pack -- on its compute stream
     for (uint32_t i = 0; i < n; ++i) {
         Rank &r = m->ranks[i];
         RTM_HIP(m, hipSetDevice(r.device));
-        // the slot's previous frame must have left these buffers: with RCCL the rank's own exchange
-        // stream knows, with peer copies the first device's (it pulled them)
-        Rank &freed_by = m->use_rccl ? r : root;
-        if (freed_by.exchanged_valid[slot])
-            RTM_HIP(m, hipStreamWaitEvent(r.compute, freed_by.exchanged[slot], 0));
-        RTM_HIP(m, hipMemsetAsync(r.sums[slot], 0, count * sizeof(uint32_t), r.compute));
-        rt_params p = *params;
-        bool has_work = true;
-        if (tiles) {
-            p.tile_first = i;
-            p.tile_stride = n;
-        } else {
-            sample_slice(params->spp, i, n, p.sample_begin, p.sample_count);
-            has_work = p.sample_count != 0u; // more ranks than samples: nothing to add
-            if (n == 1u)
-                p.sample_begin = p.sample_count = 0u;
+        rt_job jobs[RT_MAX_JOBS];
+        uint32_t n_jobs = 0u;
+        for (uint32_t f = 0; f < n_frames; ++f) {
+            const int slot = slots[f];
+            // the slot's previous frame must have left these buffers: with RCCL the rank's own exchange
+            // stream knows, with peer copies the first device's (it pulled them)
+            Rank &freed_by = m->use_rccl ? r : root;
+            if (freed_by.exchanged_valid[slot])
+                RTM_HIP(m, hipStreamWaitEvent(r.compute, freed_by.exchanged[slot], 0));
+            RTM_HIP(m, hipMemsetAsync(r.sums[slot], 0, (size_t)params[f].width * params[f].height * 3u * sizeof(uint32_t),
+                                      r.compute));
+            rt_params p = params[f];
+            if (tiles) {
+                p.tile_first = i;
+                p.tile_stride = n;
+            } else {
+                sample_slice(p.spp, i, n, p.sample_begin, p.sample_count);
+                if (p.sample_count == 0u)
+                    continue; // more ranks than samples: nothing to add
+                if (n == 1u)
+                    p.sample_begin = p.sample_count = 0u;
+            }
+            rt_job &j = jobs[n_jobs++];
+            memset(&j, 0, sizeof j);
+            j.cam = cams[f];
+            j.params = p;
+            j.xsize = (int)p.width;
+            j.ysize = (int)p.height;
+            j.d_sums = r.sums[slot];
         }
-        if (has_work)
-            RTM_RT(m, r, rt_accumulate_device(r.ctx, cam, &p, 0, 0, (int)W, (int)H, r.sums[slot], r.compute));
-        if (tiles) {
-            uint8_t *dst = (i == 0 && !m->use_rccl) ? m->blocks[slot] : r.block[slot];
-            RTM_RT(m, r, rt_pack_tiles_device(r.ctx, r.sums[slot], W, H, params->spp, params->flags & RT_FLAG_GAMMA2,
-                                              i, n, dst, r.compute));
+        if (n_jobs == 1u) // (one job: the entry point that also takes calls too large for one launch)
+            RTM_RT(m, r, rt_accumulate_device(r.ctx, &jobs[0].cam, &jobs[0].params, 0, 0, jobs[0].xsize, jobs[0].ysize,
+                                              jobs[0].d_sums, r.compute));
+        else if (n_jobs > 1u)
+            RTM_RT(m, r, rt_accumulate_batch_device(r.ctx, jobs, n_jobs, r.compute));
+        for (uint32_t f = 0; f < n_frames; ++f) {
+            const int slot = slots[f];
+            const rt_params &p = params[f];
+            if (tiles) {
+                uint8_t *dst = (i == 0 && !m->use_rccl) ? m->blocks[slot] : r.block[slot];
+                RTM_RT(m, r, rt_pack_tiles_device(r.ctx, r.sums[slot], p.width, p.height, p.spp, p.flags & RT_FLAG_GAMMA2,
+                                                  i, n, dst, r.compute));
+            }
+            RTM_HIP(m, hipEventRecord(r.traced[slot], r.compute));
         }
-        RTM_HIP(m, hipEventRecord(r.traced[slot], r.compute));
-        RTM_HIP(m, hipStreamWaitEvent(r.comm, r.traced[slot], 0));
     }
 
-    // ---- the exchange, on the exchange streams
-    if (m->use_rccl) {
-        // One group for all ranks' calls (one thread drives every communicator).  Sample slices: every
-        // rank's sums reduced in place into the first rank's.  Tiles: every rank, the first included,
-        // sends its block to the first, which receives block j at offset j of the gather buffer -- with
-        // one device this is the first rank sending to itself, the same calls as with eight.
-        RTM_NCCL(m, m->rccl.GroupStart());
+    // ---- frame by frame: the exchange, on the exchange streams, and the first device's last step
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        const int slot = slots[f];
+        const rt_params &p = params[f];
+        const uint32_t W = p.width, H = p.height;
+        const size_t count = (size_t)W * H * 3u;
+        const size_t bb = (size_t)rt_tile_block_bytes(W, H, 0u, n);
         for (uint32_t i = 0; i < n; ++i) {
             Rank &r = m->ranks[i];
-            ncclResult_t e = ncclSuccess;
-            if (!tiles) {
-                e = m->rccl.Reduce(r.sums[slot], r.sums[slot], count, ncclUint32, ncclSum, 0, r.nccl, r.comm);
-            } else {
-                if (i == 0)
-                    for (uint32_t j = 0; j < n && e == ncclSuccess; ++j)
-                        e = m->rccl.Recv(m->blocks[slot] + (size_t)j * bb, bb, ncclUint8, (int)j, r.nccl, r.comm);
-                if (e == ncclSuccess)
-                    e = m->rccl.Send(r.block[slot], bb, ncclUint8, 0, r.nccl, r.comm);
-            }
-            if (e != ncclSuccess) {
-                (void)m->rccl.GroupEnd();
-                return fail(m, RT_ERR_HIP, std::string("RCCL exchange: ") + m->rccl.GetErrorString(e));
-            }
+            RTM_HIP(m, hipSetDevice(r.device));
+            RTM_HIP(m, hipStreamWaitEvent(r.comm, r.traced[slot], 0));
         }
-        RTM_NCCL(m, m->rccl.GroupEnd());
-    } else if (n > 1u) {
-        // peer copies: the first device waits for every rank's share, then pulls it
-        RTM_HIP(m, hipSetDevice(root.device));
-        for (uint32_t i = 1; i < n; ++i)
-            RTM_HIP(m, hipStreamWaitEvent(root.comm, m->ranks[i].traced[slot], 0));
-        if (tiles) {
-            for (uint32_t i = 1; i < n; ++i) {
-                uint8_t *dst = m->blocks[slot] + (size_t)i * bb;
-                if (m->ranks[i].device == root.device)
-                    RTM_HIP(m, hipMemcpyAsync(dst, m->ranks[i].block[slot], bb, hipMemcpyDeviceToDevice, root.comm));
-                else
-                    RTM_HIP(m, hipMemcpyPeerAsync(dst, root.device, m->ranks[i].block[slot], m->ranks[i].device, bb,
-                                                  root.comm));
+        if (m->use_rccl) {
+            // One group for all ranks' calls (one thread drives every communicator).  Sample slices: every
+            // rank's sums reduced in place into the first rank's.  Tiles: every rank, the first included,
+            // sends its block to the first, which receives block j at offset j of the gather buffer -- with
+            // one device this is the first rank sending to itself, the same calls as with eight.
+            RTM_NCCL(m, m->rccl.GroupStart());
+            for (uint32_t i = 0; i < n; ++i) {
+                Rank &r = m->ranks[i];
+                ncclResult_t e = ncclSuccess;
+                if (!tiles) {
+                    e = m->rccl.Reduce(r.sums[slot], r.sums[slot], count, ncclUint32, ncclSum, 0, r.nccl, r.comm);
+                } else {
+                    if (i == 0)
+                        for (uint32_t j = 0; j < n && e == ncclSuccess; ++j)
+                            e = m->rccl.Recv(m->blocks[slot] + (size_t)j * bb, bb, ncclUint8, (int)j, r.nccl, r.comm);
+                    if (e == ncclSuccess)
+                        e = m->rccl.Send(r.block[slot], bb, ncclUint8, 0, r.nccl, r.comm);
+                }
+                if (e != ncclSuccess) {
+                    (void)m->rccl.GroupEnd();
+                    return fail(m, RT_ERR_HIP, std::string("RCCL exchange: ") + m->rccl.GetErrorString(e));
+                }
             }
-        } else {
-            AddArgs a;
-            memset(&a, 0, sizeof a);
-            a.dst = root.sums[slot];
-            a.count = count;
-            a.n_src = n - 1u;
+            RTM_NCCL(m, m->rccl.GroupEnd());
+        } else if (n > 1u) {
+            // peer copies: the first device waits for every rank's share, then pulls it
+            RTM_HIP(m, hipSetDevice(root.device));
             for (uint32_t i = 1; i < n; ++i)
-                a.src[i - 1u] = m->ranks[i].sums[slot];
-            RTM_HIP(m, launch_add_sums(a, root.comm));
+                RTM_HIP(m, hipStreamWaitEvent(root.comm, m->ranks[i].traced[slot], 0));
+            if (tiles) {
+                for (uint32_t i = 1; i < n; ++i) {
+                    uint8_t *dst = m->blocks[slot] + (size_t)i * bb;
+                    if (m->ranks[i].device == root.device)
+                        RTM_HIP(m, hipMemcpyAsync(dst, m->ranks[i].block[slot], bb, hipMemcpyDeviceToDevice, root.comm));
+                    else
+                        RTM_HIP(m, hipMemcpyPeerAsync(dst, root.device, m->ranks[i].block[slot], m->ranks[i].device, bb,
+                                                      root.comm));
+                }
+            } else {
+                AddArgs a;
+                memset(&a, 0, sizeof a);
+                a.dst = root.sums[slot];
+                a.count = count;
+                a.n_src = n - 1u;
+                for (uint32_t i = 1; i < n; ++i)
+                    a.src[i - 1u] = m->ranks[i].sums[slot];
+                RTM_HIP(m, launch_add_sums(a, root.comm));
+            }
+        }
+
+        // ---- the first device: FinalColor / SPP and PutPixel (Source/main.cpp:638-642)
+        RTM_HIP(m, hipSetDevice(root.device));
+        if (tiles)
+            RTM_RT(m, root, rt_unpack_tiles_device(root.ctx, m->blocks[slot], n, bb, W, H, d_rgb[f], root.comm));
+        else
+            RTM_RT(m, root, rt_resolve_device(root.ctx, root.sums[slot], W, H, p.spp, p.flags & RT_FLAG_GAMMA2,
+                                              0, 0, (int)W, (int)H, d_rgb[f], root.comm));
+        RTM_HIP(m, hipEventRecord(root.exchanged[slot], root.comm));
+        root.exchanged_valid[slot] = true;
+        for (uint32_t i = 1; i < n && m->use_rccl; ++i) {
+            Rank &r = m->ranks[i];
+            RTM_HIP(m, hipSetDevice(r.device));
+            RTM_HIP(m, hipEventRecord(r.exchanged[slot], r.comm));
+            r.exchanged_valid[slot] = true;
         }
     }
-
-    // ---- the first device: FinalColor / SPP and PutPixel (Source/main.cpp:638-642)
-    RTM_HIP(m, hipSetDevice(root.device));
-    if (tiles)
-        RTM_RT(m, root, rt_unpack_tiles_device(root.ctx, m->blocks[slot], n, bb, W, H, d_rgb, root.comm));
-    else
-        RTM_RT(m, root, rt_resolve_device(root.ctx, root.sums[slot], W, H, params->spp, params->flags & RT_FLAG_GAMMA2,
-                                          0, 0, (int)W, (int)H, d_rgb, root.comm));
-    RTM_HIP(m, hipEventRecord(root.exchanged[slot], root.comm));
-    root.exchanged_valid[slot] = true;
-    for (uint32_t i = 1; i < n && m->use_rccl; ++i) {
-        Rank &r = m->ranks[i];
-        RTM_HIP(m, hipSetDevice(r.device));
-        RTM_HIP(m, hipEventRecord(r.exchanged[slot], r.comm));
-        r.exchanged_valid[slot] = true;
-    }
-    ++m->frames;
+    m->frames += n_frames;
     return RT_OK;
 }
 

@@ -34,7 +34,7 @@ EXPORTS = [
     "rt_camera_init", "rt_render", "rt_render_progressive", "rt_render_device", "rt_render_device_static", "rt_accumulate_device", "rt_accumulate_batch_device", "rt_resolve_device",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_device_count", "rt_multi_uses_rccl",
     "rt_multi_context", "rt_multi_set_scene", "rt_multi_set_option", "rt_multi_render", "rt_multi_render_device",
-    "rt_multi_synchronize", "rt_multi_get_stats", "rt_multi_reset_stats",
+    "rt_multi_render_frames_device", "rt_multi_synchronize", "rt_multi_get_stats", "rt_multi_reset_stats",
     "rt_tile_block_bytes", "rt_pack_tiles_device", "rt_unpack_tiles_device", "rt_primary_hits", "rt_primary_hits_device", "rt_intersect", "rt_set_option", "rt_get_option", "rt_accel_selfcheck", "rt_get_stats", "rt_reset_stats", "rt_get_work_profile",
 ]
 
@@ -151,6 +151,8 @@ def load():
     L.rt_multi_set_option.argtypes = [vp, i, C.c_int64]
     L.rt_multi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, vp]
     L.rt_multi_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), i, vp]
+    if hasattr(L, "rt_multi_render_frames_device"):
+        L.rt_multi_render_frames_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), u32, i, C.POINTER(vp)]
     L.rt_multi_synchronize.argtypes = [vp]
     L.rt_multi_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_multi_reset_stats.argtypes = [vp]
@@ -424,6 +426,14 @@ class Multi:
 
     def render_device(self, cam, p, partition, d_rgb):
         self._check(self._L.rt_multi_render_device(self._h, C.byref(cam), C.byref(p), partition, d_rgb))
+
+    def render_frames_device(self, frames, partition):
+        """frames: [(cam, params, d_rgb address), ...], at most MAX_JOBS -- one trace launch per device for all of them."""
+        n = len(frames)
+        cams = (Camera * n)(*[f[0] for f in frames])
+        ps = (Params * n)(*[f[1] for f in frames])
+        out = (C.c_void_p * n)(*[f[2] for f in frames])
+        self._check(self._L.rt_multi_render_frames_device(self._h, cams, ps, n, partition, out))
 
     def synchronize(self):
         self._check(self._L.rt_multi_synchronize(self._h))

@@ -136,6 +136,60 @@ def test_multi_pipelined_frames_on_device(tmp_path):
         ctx.close()
 
 
+@pytest.mark.parametrize("ids,exchange", [([0], rtamd.EXCHANGE_RCCL), ([0, 0, 0], rtamd.EXCHANGE_PEER_COPY),
+                                          ([0] * 8, rtamd.EXCHANGE_AUTO)])
+def test_multi_several_frames_per_call(ids, exchange):
+    """rt_multi_render_frames_device: every rank traces its shares of a call's frames in one launch; the
+    pictures are those of single-frame calls, for frames of different cameras, sizes and sample counts, calls
+    of different lengths one after the other (the buffer sets rotate and grow), and single frames in between."""
+    import torch
+
+    sc = c3_scene()
+    ctx = rtamd.Context(0)
+    ctx.set_scene(sc)
+    cams = [rtamd.make_camera((13 - k, 2 + 0.25 * k, 3 + 0.5 * k), (0, 0, 0), (0, 1, 0), 20 + k) for k in range(8)]
+    shapes = [(160, 90, 5), (96, 54, 3), (200, 120, 2), (160, 90, 9), (64, 40, 1), (160, 90, 5), (100, 61, 6), (128, 72, 4)]
+    frames = [(cams[k], rtamd.params(w, h, spp, 8, seed=12)) for k, (w, h, spp) in enumerate(shapes)]
+    want = [ctx.render(c, p) for c, p in frames]
+    rays = []
+    for c, p in frames:
+        ctx.reset_stats()
+        ctx.render(c, p)
+        rays.append(ctx.stats().rays)
+    ctx.close()
+    m = rtamd.Multi(ids, exchange)
+    try:
+        m.set_scene(sc)
+        for partition in (rtamd.PARTITION_SAMPLES, rtamd.PARTITION_TILES):
+            for cut in ([8], [3, 1, 4], [1, 2, 2, 1, 2], [5, 3]):
+                outs = [torch.zeros(p.height * p.width * 3, dtype=torch.uint8, device="cuda") for _, p in frames]
+                torch.cuda.synchronize()
+                m.reset_stats()
+                at = 0
+                for n in cut:
+                    group = [(frames[k][0], frames[k][1], outs[k].data_ptr()) for k in range(at, at + n)]
+                    if n == 1:
+                        m.render_device(group[0][0], group[0][1], partition, group[0][2])
+                    else:
+                        m.render_frames_device(group, partition)
+                    at += n
+                m.synchronize()
+                for k, (o, w) in enumerate(zip(outs, want)):
+                    p = frames[k][1]
+                    assert np.array_equal(o.cpu().numpy().reshape(p.height, p.width, 3), w), (partition, cut, k)
+                assert m.stats().rays == sum(rays)
+        # the frames of a call share seed and flags; a refused call leaves the object usable
+        bad = [(cams[0], rtamd.params(64, 40, 2, 8, seed=1), outs[0].data_ptr()),
+               (cams[1], rtamd.params(64, 40, 2, 8, seed=2), outs[1].data_ptr())]
+        with pytest.raises(rtamd.RtError, match="share seed and flags"):
+            m.render_frames_device(bad, rtamd.PARTITION_TILES)
+        with pytest.raises(rtamd.RtError, match="RT_MAX_JOBS"):
+            m.render_frames_device([(cams[0], frames[0][1], outs[0].data_ptr())] * 9, rtamd.PARTITION_TILES)
+        assert np.array_equal(m.render(frames[0][0], frames[0][1], rtamd.PARTITION_SAMPLES), want[0])
+    finally:
+        m.close()
+
+
 def test_multi_full_size_frame_and_bad_arguments():
     sc = c3_scene()
     cam = rtamd.make_camera(*C3_CAM)
