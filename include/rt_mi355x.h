@@ -325,8 +325,9 @@ typedef enum rt_option {
     RT_OPT_FILTER = 0,
     RT_OPT_TILE_SPHERES = 1,      /* spheres per LDS tile, 128..4096 (default 512) */
     RT_OPT_WORKGROUPS_PER_CU = 2, /* cap on resident workgroups per CU, 0 = occupancy limit */
-    RT_OPT_BVH_LEAF_SPHERES = 3,  /* most spheres per leaf of the hierarchy, 1..15, or 0 (default) = by scene size: 4, or 8 for
-                                     trees too large for LDS */
+    RT_OPT_BVH_LEAF_SPHERES = 3,  /* most spheres per leaf of the hierarchy, 1..15, or 0 (default) = chosen when the tree is
+                                     built: the smallest of 4, 8, 12, 15 whose tree, copied to LDS, leaves room for seven
+                                     workgroups per CU, else the largest that LDS may hold, or 8 for trees walked in memory */
     RT_OPT_BVH_MIN_SPHERES = 4,   /* scene size from which the automatic choice is the hierarchy (default 13) */
     RT_OPT_BVH_LDS_NODES = 5,     /* hierarchies of up to this many nodes (and at most 2048 sphere records) are walked
                                      in LDS, 0..2048 (default 512) */

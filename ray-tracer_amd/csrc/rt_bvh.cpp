@@ -132,8 +132,13 @@ struct Builder {
 
     // Binned SAH: reorders items[first, first+count) and returns the size of the
     // left part, or 0 when no bin boundary separates the set.
+    // What a side of a split costs is its box's area times its spheres -- or, where leaves hold more than
+    // four, times its groups of four: the walk tests a leaf's records four at a time, so a leaf of five
+    // costs what a leaf of eight does (10 000 spheres in leaves of up to 8: 13.25 -> 12.87 ms per
+    // 1080p / 64 spp frame; leaves of up to 4 are one group whatever they hold, and keep the count).
     uint32_t sah_partition(uint32_t first, uint32_t count, const Box &cb)
     {
+        const bool by_groups = leaf_max > 4;
         double best_cost = std::numeric_limits<double>::infinity();
         int best_axis = -1, best_bin = -1;
         for (int axis = 0; axis < 3; ++axis) {
@@ -168,7 +173,8 @@ struct Builder {
                 n_acc += bn[b];
                 if (n_acc == 0 || right_n[b + 1] == 0)
                     continue;
-                const double cost = acc.half_area() * n_acc + right_area[b + 1] * right_n[b + 1];
+                const double cost = by_groups ? acc.half_area() * ((n_acc + 3u) / 4u) + right_area[b + 1] * ((right_n[b + 1] + 3u) / 4u)
+                                              : acc.half_area() * n_acc + right_area[b + 1] * right_n[b + 1];
                 if (cost < best_cost) {
                     best_cost = cost;
                     best_axis = axis;

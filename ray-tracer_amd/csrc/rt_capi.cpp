@@ -47,7 +47,7 @@ struct rt_context {
     std::vector<Geom> h_exact;
     BvhHost bvh;                   // host copy of what d_bvh_* hold
     bool bvh_ready = false;
-    int bvh_leaf_max = 0;          // RT_OPT_BVH_LEAF_SPHERES; 0 = by scene size (chosen_leaf_spheres())
+    int bvh_leaf_max = 0;          // RT_OPT_BVH_LEAF_SPHERES; 0 = chosen by trial (build_hierarchy())
     uint32_t bvh_suspend_lanes = 16;  // see RT_OPT_BVH_SUSPEND_LANES
     uint32_t bvh_lds_nodes_max = 512; // trees up to this many nodes (64 B each) are walked in LDS
     uint32_t subtiles_max = 8;     // work queue: tiles may be cut into this many strips of rows (1, 2, 4 or 8)
@@ -251,14 +251,41 @@ void drop_bvh(rt_context *ctx)
     ctx->bvh_ready = false;
 }
 
-// Most spheres per leaf: 4 while the tree's nodes fit the LDS copy the kernels walk (measured best
-// on the 500-sphere frame), 8 for trees walked through the caches, where a node visit costs more
-// than a few more exact tests (10 000 spheres: 4 % faster than 4).
-int chosen_leaf_spheres(const rt_context *ctx)
+// Builds the hierarchy with the leaf size the options ask for, or (RT_OPT_BVH_LEAF_SPHERES 0) chosen by
+// trial.  A tree walked in LDS costs LDS, and with it resident waves: leaves of up to 4 are best while
+// the node copy leaves room for seven workgroups per CU (the 500-sphere frame: 162 nodes), but 1 000
+// spheres in leaves of 4 are 309 nodes and five workgroups, 1 500 are 496 nodes and three.  So: the
+// smallest of 4, 8, 12, 15 whose tree still leaves seven workgroups per CU (at eight bounces), else the
+// fewest nodes LDS may hold (1080p / 32 spp, ms: 700 spheres 4.00 -> 3.59, 1 000 4.62 -> 3.80, 1 500
+// 5.89 -> 4.03, 2 000 4.92 -> 4.24).  Trees that cannot be walked in LDS at all (more than
+// kBvhLdsRecords spheres, or more nodes than RT_OPT_BVH_LDS_NODES at every size) get 8: there a node
+// visit costs more than a few more exact tests (10 000 spheres: 4 % faster than 4).
+void build_hierarchy(const rt_context *ctx, BvhHost &b)
 {
-    if (ctx->bvh_leaf_max > 0)
-        return ctx->bvh_leaf_max;
-    return (uint64_t)ctx->n_spheres <= 4ull * ctx->bvh_lds_nodes_max ? 4 : 8;
+    const rt_sphere *sp = ctx->h_spheres.data();
+    const Geom *ex = ctx->h_exact.data();
+    if (ctx->bvh_leaf_max > 0) {
+        bvh_build(sp, ex, ctx->n_spheres, ctx->bvh_leaf_max, b);
+        return;
+    }
+    if (ctx->bvh_lds_nodes_max > 0u && ctx->n_spheres <= kBvhLdsRecords) {
+        bool have = false;
+        for (int leaf : { 4, 8, 12, 15 }) {
+            BvhHost t;
+            bvh_build(sp, ex, ctx->n_spheres, leaf, t);
+            const uint32_t nodes = (uint32_t)t.nodes.size(), levels = t.levels ? t.levels : 1u;
+            if (nodes > ctx->bvh_lds_nodes_max)
+                continue; // would be walked through the caches
+            const size_t lds = trace_lds_bytes(kFilterBvh, 0u, trace_aux_bytes(kFilterBvh, levels, nodes), 8, 2u);
+            b = std::move(t);
+            have = true;
+            if (lds * 7u <= 160u * 1024u)
+                return;
+        }
+        if (have)
+            return; // the largest leaves that fit: the fewest nodes
+    }
+    bvh_build(sp, ex, ctx->n_spheres, 8, b);
 }
 
 // Builds the hierarchy over the current scene and copies it to the device (once per scene
@@ -273,7 +300,7 @@ int ensure_bvh(rt_context *ctx, const BvhHost *prebuilt = nullptr)
     if (prebuilt)
         b = *prebuilt;
     else
-        bvh_build(ctx->h_spheres.data(), ctx->h_exact.data(), ctx->n_spheres, chosen_leaf_spheres(ctx), b);
+        build_hierarchy(ctx, b);
     if (b.levels > 96u)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "hierarchy deeper than 96 levels");
     // the kernels follow child references and leaf ranges without bounds checks: make sure on the
@@ -768,7 +795,7 @@ int rtamd::set_scene_sharing_hierarchy(rt_context *ctx, const rt_sphere *spheres
     if (chosen_filter(ctx) == kFilterBvh) {
         const BvhHost *prebuilt = nullptr;
         if (donor && donor != ctx && donor->bvh_ready && donor->n_spheres == n &&
-            chosen_leaf_spheres(donor) == chosen_leaf_spheres(ctx) &&
+            donor->bvh_leaf_max == ctx->bvh_leaf_max && donor->bvh_lds_nodes_max == ctx->bvh_lds_nodes_max &&
             (n == 0u || memcmp(donor->h_spheres.data(), spheres, (size_t)n * sizeof(rt_sphere)) == 0))
             prebuilt = &donor->bvh;
         return ensure_bvh(ctx, prebuilt);
@@ -1421,9 +1448,9 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
     case RT_OPT_BVH_LEAF_SPHERES: {
         if (value < 0 || value > kBvhLeafMax)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_LEAF_SPHERES takes 0 (by scene size) or 1..15");
-        const int before = chosen_leaf_spheres(ctx);
+        const int before = ctx->bvh_leaf_max;
         ctx->bvh_leaf_max = (int)value;
-        if (ctx->bvh_ready && chosen_leaf_spheres(ctx) != before) { // the tree on the device has another shape
+        if (ctx->bvh_ready && ctx->bvh_leaf_max != before) { // the tree on the device may have another shape
             RT_DEVICE(ctx);
             RT_HIP(ctx, hipDeviceSynchronize());
             drop_bvh(ctx);
@@ -1433,11 +1460,11 @@ int rt_set_option(rt_context *ctx, int option, int64_t value)
     case RT_OPT_BVH_LDS_NODES: {
         if (value < 0 || value > 2048)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BVH_LDS_NODES takes 0..2048");
-        // the automatic leaf size depends on whether the tree is expected to fit LDS: a tree built for
-        // the old limit is dropped and (below) rebuilt when the new limit chooses another
-        const int before = chosen_leaf_spheres(ctx);
+        // the automatic leaf size depends on what LDS may hold: a tree built for the old limit is
+        // dropped and (below) rebuilt
+        const uint32_t before = ctx->bvh_lds_nodes_max;
         ctx->bvh_lds_nodes_max = (uint32_t)value;
-        if (ctx->bvh_ready && chosen_leaf_spheres(ctx) != before) {
+        if (ctx->bvh_ready && ctx->bvh_leaf_max == 0 && ctx->bvh_lds_nodes_max != before) {
             RT_DEVICE(ctx);
             RT_HIP(ctx, hipDeviceSynchronize());
             drop_bvh(ctx);
