@@ -390,7 +390,10 @@ def main():
         else:
             roof.update({"bound": "valu", "pipe": "vector ALU issue (the kernel executes no MFMA)",
                          "achieved": None, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlaneop/s", "frac": None,
-                         "basis": "no counter profile of this build (profile stale or absent): achieved and frac left null"})
+                         "basis": ("no counter profile of this build (profile stale or absent): achieved and frac left null"
+                                   if args.workload == "c3" and world == 1 and per_launch == 1 else
+                                   "the committed counter profile is of the default one-GPU command (one 1080p / 64 spp frame "
+                                   "per launch): achieved and frac left null for this one")})
             if prof and "SQ_INSTS_VALU" in prof and "derived" in prof and prof["derived"].get("valu_active_lane_share"):
                 d = prof["derived"]
                 lane_ops = prof["SQ_INSTS_VALU"] * 64.0 * d["valu_active_lane_share"]
