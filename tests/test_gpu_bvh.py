@@ -43,7 +43,7 @@ def test_reference_scene_and_random_spheres(ctx, leaf):
         same_as_oracle(ctx, sc, C3_CAM, 160, 90, 4, 8, 1)
         same_as_oracle(ctx, sc, C3_CAM, 96, 54, 4, 12, 3, flags=rtamd.FLAG_DIELECTRIC)  # rays from inside spheres
     finally:
-        ctx.set_option(rtamd.OPT_BVH_LEAF_SPHERES, 4)
+        ctx.set_option(rtamd.OPT_BVH_LEAF_SPHERES, 0)  # the shipped setting: chosen when the tree is built
 
 
 def test_ten_thousand_spheres(ctx):
@@ -64,7 +64,23 @@ def test_trees_at_the_limit_of_two_byte_stack_entries(ctx, n):
         assert st == 0 and nodes <= 512 and records == n
         same_as_oracle(ctx, scenes.random_spheres(n, grid_half=24, seed=3), C3_CAM, 96, 54, 2, 8, 11)
     finally:
-        ctx.set_option(rtamd.OPT_BVH_LEAF_SPHERES, 4)
+        ctx.set_option(rtamd.OPT_BVH_LEAF_SPHERES, 0)  # the shipped setting: chosen when the tree is built
+
+
+@pytest.mark.parametrize("n,grid", [(170, 7), (700, 13), (1000, 16), (1500, 19), (2000, 22), (2048, 23), (2049, 23), (3000, 27)])
+def test_leaf_size_chosen_by_the_library(ctx, n, grid):
+    """With RT_OPT_BVH_LEAF_SPHERES 0 (shipped) the library builds the tree with leaves of up to 4, 8, 12 or
+    15 spheres, whichever keeps the LDS copy small enough (or 8 for trees walked in memory): scene sizes on
+    either side of every switch, against the oracle, and against the same scene under a forced leaf size."""
+    assert ctx.get_option(rtamd.OPT_BVH_LEAF_SPHERES) == 0
+    sc = scenes.random_spheres(n, grid_half=grid, seed=n)
+    auto = same_as_oracle(ctx, sc, C3_CAM, 96, 54, 2, 8, 21)
+    ctx.set_option(rtamd.OPT_BVH_LEAF_SPHERES, 5)
+    try:
+        ctx.reset_stats()
+        assert np.array_equal(ctx.render(rtamd.make_camera(*C3_CAM), rtamd.params(96, 54, 2, 8, seed=21)), auto)
+    finally:
+        ctx.set_option(rtamd.OPT_BVH_LEAF_SPHERES, 0)
 
 
 def test_hundred_thousand_spheres_walked_from_memory(ctx):
