@@ -119,9 +119,16 @@ __device__ __forceinline__ float max_abs(float x, float m)
     return o;
 }
 
-// Start of a ray's walk: the always-tested spheres, then the root.
+// The reference to node `index` of a tree copied to LDS at `lds_nodes`: the node's LDS address (inner
+// nodes' references are >= 0 either way; leaf codes and kBvhDone are negative).
+__device__ __forceinline__ int lds_node_reference(const float4 *lds_nodes, int index)
+{
+    return (int)(uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds_nodes + (index << 6);
+}
+
+// Start of a ray's walk: the always-tested spheres, then the root (`root`: its reference).
 __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, float tmin, int &node, uint32_t &sp,
-                                          float &closest, int &best, WorkCount *wc = nullptr)
+                                          float &closest, int &best, WorkCount *wc = nullptr, int root = 0)
 {
     closest = INFINITY;
     best = -1;
@@ -137,7 +144,7 @@ __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, f
         g.cx = lg[4u * i + 0u]; g.cy = lg[4u * i + 1u]; g.cz = lg[4u * i + 2u]; g.r2 = lg[4u * i + 3u];
         resolve_unordered_tame(r, g, (int)li[i], tmin, closest, best, wc);
     }
-    node = b.n_nodes ? 0 : kBvhDone;
+    node = b.n_nodes ? root : kBvhDone;
     sp = 0u;
 }
 
@@ -197,11 +204,26 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
                 ++wc->nodes;
             RT_TALLY(wc, kSecNode);
             // (a tree in memory: the node's byte offset as an unsigned 32-bit number, which the load
-            // takes next to the array's address in scalar registers -- no 64-bit address arithmetic)
-            const float4 *np = NODES_IN_LDS ? lds_nodes + (size_t)node * 4u
-                                            : reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(b.nodes) +
-                                                                               ((uint32_t)node << 6));
-            const float4 l0 = np[0], h0 = np[1], l1 = np[2], h1 = np[3];
+            // takes next to the array's address in scalar registers -- no 64-bit address arithmetic;
+            // a tree in LDS: the reference IS the node's LDS address, see lds_node_reference)
+            // (the second box's quadwords end in padding: three words each)
+            typedef float f32x3 __attribute__((ext_vector_type(3)));
+            f32x4 l0, h0;
+            f32x3 l1, h1;
+            if (NODES_IN_LDS) {
+                typedef const __attribute__((address_space(3))) char *LdsNode;
+                const LdsNode np = (LdsNode)(uintptr_t)(uint32_t)node;
+                l0 = *(const __attribute__((address_space(3))) f32x4 *)(np);
+                h0 = *(const __attribute__((address_space(3))) f32x4 *)(np + 16);
+                l1 = *(const __attribute__((address_space(3))) f32x3 *)(np + 32);
+                h1 = *(const __attribute__((address_space(3))) f32x3 *)(np + 48);
+            } else {
+                const char *np = reinterpret_cast<const char *>(b.nodes) + ((uint32_t)node << 6);
+                l0 = *reinterpret_cast<const f32x4 *>(np);
+                h0 = *reinterpret_cast<const f32x4 *>(np + 16);
+                l1 = *reinterpret_cast<const f32x3 *>(np + 32);
+                h1 = *reinterpret_cast<const f32x3 *>(np + 48);
+            }
 #define RT_SLAB(lo, hi, na, nb, nc) __builtin_fmaf(lo, na, __builtin_fmaf(hi, nb, nc))
             const float n0 = fmaxf(fmaxf(fmaxf(RT_SLAB(l0.x, h0.x, nax, nbx, ncx), RT_SLAB(l0.y, h0.y, nay, nby, ncy)),
                                          RT_SLAB(l0.z, h0.z, naz, nbz, ncz)), t_lo);

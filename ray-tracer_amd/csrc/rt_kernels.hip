@@ -251,7 +251,9 @@ trace_kernel(const TraceArgs a)
     Geom *tile_e = FILTER == kFilterMatrix ? tile_f : tile_f + a.tile_cap;
     // matrix scan: 4 waves x 9 x 64 floats of operand staging; hierarchy scan: the walk's
     // stack, levels x 256 node references
-    float *stage = reinterpret_cast<float *>(tile_e + a.tile_cap);
+    // (the walking kernels have no tiles: their area starts the workgroup's LDS, at a constant address)
+    float *stage = FILTER == kFilterBvh || FILTER == kFilterShort ? reinterpret_cast<float *>(smem)
+                                                                  : reinterpret_cast<float *>(tile_e + a.tile_cap);
     uint32_t *stack = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(stage) + a.aux_bytes);
     const int stack_levels = a.max_depth > 0 ? a.max_depth : 1;
     uint32_t *wave_flags = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(stack) +
@@ -270,18 +272,27 @@ trace_kernel(const TraceArgs a)
         load_tile(tile_f, FILTER == kFilterMatrix ? nullptr : tile_e, filt_src, a.exact, 0u, n_pad);
         __syncthreads();
     }
-    // hierarchy scan: the nodes of a small tree live in LDS, behind the walk's stack (whose entries
-    // are two bytes then, four for a tree walked in memory)
-    float4 *bvh_lds = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(stage) +
-                                                 (size_t)a.bvh.levels * kTraceThreads * (a.bvh.lds_nodes ? 2u : 4u));
+    // hierarchy scan: the nodes of a small tree live at the start of LDS, the walk's stack behind them
+    // (its entries are two bytes then, four for a tree walked in memory).  In the LDS copy a child
+    // reference to an inner node is that node's LDS address (below 2^15: it fits the stack's two
+    // bytes), so the walk reads a node at the address its reference is, with no arithmetic.
+    float4 *bvh_lds = reinterpret_cast<float4 *>(stage);
+    unsigned char *walk_stack = reinterpret_cast<unsigned char *>(stage) + (size_t)a.bvh.lds_nodes * 64u;
     // 64 bytes per wave for unit_sphere_points_wave: the head of the wave's own operand staging
     // slice in the matrix scan (idle while paths are shaded), else a region of its own
     uint8_t *coop = FILTER == kFilterBvh
-                        ? reinterpret_cast<uint8_t *>(bvh_lds + (size_t)a.bvh.lds_nodes * 4u) + (threadIdx.x >> 6) * 64
+                        ? walk_stack + (size_t)a.bvh.levels * kTraceThreads * (a.bvh.lds_nodes ? 2u : 4u) + (threadIdx.x >> 6) * 64
                         : reinterpret_cast<uint8_t *>(stage) + (threadIdx.x >> 6) * (FILTER == kFilterMatrix ? 9 * 64 * 4 : 64);
     if (FILTER == kFilterBvh && a.bvh.lds_nodes) {
-        for (uint32_t i = threadIdx.x; i < a.bvh.lds_nodes * 4u; i += blockDim.x)
-            bvh_lds[i] = a.bvh.nodes[i];
+        for (uint32_t i = threadIdx.x; i < a.bvh.lds_nodes * 4u; i += blockDim.x) {
+            float4 v = a.bvh.nodes[i];
+            if ((i & 3u) < 2u) { // the node's first two quadwords end in its child references
+                const int ref = __float_as_int(v.w);
+                if (ref >= 0)
+                    v.w = __int_as_float(lds_node_reference(bvh_lds, ref));
+            }
+            bvh_lds[i] = v;
+        }
         __syncthreads();
     }
 
@@ -574,7 +585,7 @@ trace_kernel(const TraceArgs a)
             if (active && !w_pending) { // a ray that starts its scan in this pass
                 w_pending = true;
                 if (ray.tame) {
-                    bvh_begin(bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best, wc);
+                    bvh_begin(bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best, wc, NODES_IN_LDS ? lds_node_reference(bvh_lds, 0) : 0);
                 } else { // the reference's in-order loop over the whole list, from memory
                     w_closest = INFINITY;
                     w_best = -1;
@@ -589,10 +600,10 @@ trace_kernel(const TraceArgs a)
             if (wave_active) {
                 // (a lane without a path, or whose ray has finished its walk or takes none, holds kBvhDone)
                 if (NODES_IN_LDS)
-                    bvh_walk<true>(bvh, bvh_lds, ray, reinterpret_cast<int16_t *>(stage) + tid, 0.001f, w_node, w_sp,
+                    bvh_walk<true>(bvh, bvh_lds, ray, reinterpret_cast<int16_t *>(walk_stack) + tid, 0.001f, w_node, w_sp,
                                    w_closest, w_best, wc);
                 else
-                    bvh_walk<false>(bvh, nullptr, ray, reinterpret_cast<uint32_t *>(stage) + tid, 0.001f, w_node, w_sp,
+                    bvh_walk<false>(bvh, nullptr, ray, reinterpret_cast<uint32_t *>(walk_stack) + tid, 0.001f, w_node, w_sp,
                                     w_closest, w_best, wc);
             }
             if (active && w_node == kBvhDone) {
