@@ -126,9 +126,16 @@ __device__ __forceinline__ int lds_node_reference(const float4 *lds_nodes, int i
     return (int)(uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds_nodes + (index << 6);
 }
 
-// Start of a ray's walk: the always-tested spheres, then the root (`root`: its reference).
+// The LDS address of a lane's (empty) walk stack: what bvh_begin's `stack` and bvh_walk's `sp` start from.
+__device__ __forceinline__ uint32_t lds_stack_address(const void *stk)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)stk;
+}
+
+// Start of a ray's walk: the always-tested spheres, then the root (`root`: its reference; `stack`: the
+// lane's stack, lds_stack_address()).
 __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, float tmin, int &node, uint32_t &sp,
-                                          float &closest, int &best, WorkCount *wc = nullptr, int root = 0)
+                                          float &closest, int &best, uint32_t stack, WorkCount *wc = nullptr, int root = 0)
 {
     closest = INFINITY;
     best = -1;
@@ -145,7 +152,7 @@ __device__ __forceinline__ void bvh_begin(const BvhArgs &b, const RayState &r, f
         resolve_unordered_tame(r, g, (int)li[i], tmin, closest, best, wc);
     }
     node = b.n_nodes ? root : kBvhDone;
-    sp = 0u;
+    sp = stack;
 }
 
 // Must be called by all 64 lanes.  The lanes whose node is not kBvhDone walk (they hold a tame ray
@@ -197,6 +204,11 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
     const float t_lo = tmin * (1.0f - 0x1p-20f);
     float t_hi = closest * (1.0f + 0x1p-20f);
 
+    // sp: LDS address of the lane's next free stack entry (entries of one lane lie kStackStep bytes apart)
+    typedef __attribute__((address_space(3))) StackEntry *LdsStack;
+    constexpr uint32_t kStackStep = kTraceThreads * (uint32_t)sizeof(StackEntry);
+    const uint32_t stk_base = lds_stack_address(stk);
+
     constexpr int kDone = kBvhDone;
     while ((uint32_t)__popcll(wave_ballot(node != kDone)) > suspend) {
         while (node >= 0) {
@@ -238,18 +250,18 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
             const int c0 = __float_as_int(l0.w), c1 = __float_as_int(h0.w);
             if (hit0 && hit1) {
                 const bool first0 = n0 <= n1;
-                stk[sp * kTraceThreads] = (StackEntry)(first0 ? c1 : c0);
-                ++sp;
+                *(LdsStack)(uintptr_t)sp = (StackEntry)(first0 ? c1 : c0);
+                sp += kStackStep;
                 node = first0 ? c0 : c1;
             } else if (hit0) {
                 node = c0;
             } else if (hit1) {
                 node = c1;
-            } else if (sp == 0u) {
+            } else if (sp == stk_base) {
                 node = kDone;
             } else {
-                --sp;
-                node = (int)stk[sp * kTraceThreads];
+                sp -= kStackStep;
+                node = (int)*(LdsStack)(uintptr_t)sp;
             }
         }
         if (node == kDone)
@@ -257,11 +269,11 @@ __device__ __forceinline__ void bvh_walk(const BvhArgs &b, const float4 *lds_nod
         const uint32_t code = (uint32_t)~node;
         test_records(b, r, code >> 4, code & 15u, tmin, closest, best, wc);
         t_hi = closest * (1.0f + 0x1p-20f);
-        if (sp == 0u) {
+        if (sp == stk_base) {
             node = kDone;
         } else {
-            --sp;
-            node = (int)stk[sp * kTraceThreads];
+            sp -= kStackStep;
+            node = (int)*(LdsStack)(uintptr_t)sp;
         }
     }
 }
@@ -276,7 +288,7 @@ __device__ __forceinline__ void closest_hit_by_hierarchy(const BvhArgs &b, const
     uint32_t sp = 0u;
     if (have) {
         if (r.tame)
-            bvh_begin(b, r, 0.001f, node, sp, closest, best);
+            bvh_begin(b, r, 0.001f, node, sp, closest, best, lds_stack_address(stk));
         else
             scan_tile<kFilterExact>(exact, exact, n, 0u, r, 0.001f, closest, best);
     }

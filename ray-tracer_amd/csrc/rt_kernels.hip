@@ -585,7 +585,8 @@ trace_kernel(const TraceArgs a)
             if (active && !w_pending) { // a ray that starts its scan in this pass
                 w_pending = true;
                 if (ray.tame) {
-                    bvh_begin(bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best, wc, NODES_IN_LDS ? lds_node_reference(bvh_lds, 0) : 0);
+                    bvh_begin(bvh, ray, 0.001f, w_node, w_sp, w_closest, w_best,
+                              lds_stack_address(walk_stack + tid * (NODES_IN_LDS ? 2 : 4)), wc, NODES_IN_LDS ? lds_node_reference(bvh_lds, 0) : 0);
                 } else { // the reference's in-order loop over the whole list, from memory
                     w_closest = INFINITY;
                     w_best = -1;
